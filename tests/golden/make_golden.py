@@ -1,0 +1,500 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden/`` by IMPORTING AND RUNNING
+THE REFERENCE (``/root/reference/longspec``) on CPU in the build container.
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; no GPU)
+
+The reference never travels to the GPU box; only the ``.npz`` files written here
+do.  Shims installed (survey-time recipe); none of them is shipped:
+
+1. ``flash_attn`` is not installable here -> a stub module whose two functions
+   are ``oracle.ref_ops.flash_attention`` / ``kvcache_attention`` (the restated
+   flash-attn contract; "parity unpinned" for that third-party package).
+2. ``Tensor.cuda`` -> identity, ``torch.cuda.synchronize`` -> no-op.
+3. ``TORCHDYNAMO_DISABLE=1`` so ``@torch.compile`` sites run eagerly.
+4. The REAL Triton kernel ``triton_tree_attn._fwd_kernel`` runs under
+   ``TRITON_INTERPRET=1`` with stubs for the four ``torch.cuda`` device queries
+   its launcher makes (``triton_tree_attn.py:40-46,82``).
+5. transformers-5.x drift: ``config.rope_theta`` is set by hand; models are
+   constructed directly and weights loaded with ``load_state_dict``.
+
+Fixtures (SURVEY 8(c) G-a..G-g) -- everything the reference computes is stored;
+big random inputs are re-generated from seeds in the tests (checksums stored).
+"""
+import importlib.machinery
+import importlib.util
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+os.environ["TORCHDYNAMO_DISABLE"] = "1"
+os.environ["TRITON_INTERPRET"] = "1"
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+import toy
+from oracle import ref_ops
+
+REF = "/root/reference/longspec"
+torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------- #
+# shims
+# --------------------------------------------------------------------------- #
+def install_shims():
+    import transformers  # noqa: F401  (must be imported BEFORE the flash_attn stub exists)
+    from transformers.models.llama import modeling_llama  # noqa: F401
+
+    fa = types.ModuleType("flash_attn")
+    fa.__spec__ = importlib.machinery.ModuleSpec("flash_attn", None)
+
+    def flash_attn_func(q, k, v, causal=False, window_size=(-1, -1), **kw):
+        return ref_ops.flash_attention(q, k, v, causal=causal, window_size=window_size)
+
+    def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, causal=False,
+                                window_size=(-1, -1), return_softmax_lse=False, **kw):
+        return ref_ops.kvcache_attention(q, k_cache, v_cache, k, v, cache_seqlens=cache_seqlens, causal=causal,
+                                         window_size=window_size, return_softmax_lse=return_softmax_lse)
+
+    fa.flash_attn_func = flash_attn_func
+    fa.flash_attn_with_kvcache = flash_attn_with_kvcache
+    sys.modules["flash_attn"] = fa
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+
+
+def install_triton_stubs():
+    class _Dev:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    torch.cuda.device_of = lambda t: _Dev()
+    torch.cuda.device = _Dev
+    torch.cuda.get_device_properties = lambda *a, **k: SimpleNamespace(multi_processor_count=1)
+    torch.cuda.get_device_capability = lambda *a, **k: (9, 4)   # -> the "else" config (32,32,1,4)
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(REF, "test"))
+    import llama
+    import llama_glide
+    import triton_tree_attn
+    train_llama = None
+    try:
+        spec = importlib.util.spec_from_file_location("ref_train_llama", os.path.join(REF, "train/models/llama.py"))
+        train_llama = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(train_llama)
+    except Exception as e:  # pragma: no cover
+        print("WARNING: could not import train/models/llama.py:", repr(e))
+    return llama, llama_glide, triton_tree_attn, train_llama
+
+
+def hf_config(cfg):
+    from transformers import LlamaConfig
+    c = LlamaConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                    num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                    num_key_value_heads=cfg.num_key_value_heads, vocab_size=cfg.vocab_size,
+                    max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                    pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, bos_token_id=cfg.bos_token_id)
+    c.rope_theta = cfg.rope_theta
+    c.rope_parameters = {"rope_theta": cfg.rope_theta, "rope_type": "default"}
+    c._attn_implementation = "eager"
+    return c
+
+
+def build_ref_model(llama, llama_glide, cfg, tgt_sd, drf_sd):
+    hc = hf_config(cfg)
+
+    class RefGlide(llama_glide.LlamaGlide):
+        def __init__(self, config):
+            llama.LlamaForCausalLM.__init__(self, config)
+            self.glide = llama_glide.LlamaGlideDecoderLayer(config)
+
+    m = RefGlide(hc).half().eval()
+    missing, unexpected = m.load_state_dict({**tgt_sd, **{"glide." + k: v for k, v in drf_sd.items()}}, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k or "inv_freq" in k for k in missing), missing
+    return m
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu()
+            v = v.numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------- #
+# G-a: the real Triton tree kernel under the interpreter
+# --------------------------------------------------------------------------- #
+def gen_triton_tree(triton_tree_attn):
+    cases = {}
+    idx = 0
+    for (H, Hkv) in ((4, 1), (2, 2), (5, 1)):
+        for lvl, (M, N) in enumerate(((4, 5), (16, 21), (16, 37), (16, 53))):
+            seed = 4000 + idx
+            parents = toy.random_beam_tree([4, 16, 16, 16, 16], seed)
+            full = toy.tree_mask_from_parents(parents)
+            tm = torch.from_numpy(full[N - M:N, :N].copy()).unsqueeze(0)          # [1,M,N] int64
+            q = toy.randn_f16((1, H, M, 128), seed * 3 + 0)
+            k = toy.randn_f16((1, Hkv, N, 128), seed * 3 + 1)
+            v = toy.randn_f16((1, Hkv, N, 128), seed * 3 + 2)
+            o, L = triton_tree_attn.attention(q, k, v, tm)
+            tag = f"c{idx}"
+            cases.update({f"{tag}_H": H, f"{tag}_Hkv": Hkv, f"{tag}_M": M, f"{tag}_N": N, f"{tag}_seed": seed,
+                          f"{tag}_in_checksum": np.frombuffer(toy.checksum(q, k, v).encode(), dtype=np.uint8),
+                          f"{tag}_mask": tm.to(torch.int8), f"{tag}_o": o, f"{tag}_L": L})
+            idx += 1
+    save("triton_tree_attn", n_cases=idx, **cases)
+
+
+# --------------------------------------------------------------------------- #
+# G-b: LlamaAttention.tree_part_fwd ;  G-c: tree_decoding_torch (dense twin)
+# --------------------------------------------------------------------------- #
+_verify_inputs = toy.verify_inputs
+
+
+def gen_target_tree_part(llama):
+    arrays = {}
+    idx = 0
+    for last_layer in (False, True):
+        for (H, Hkv) in ((4, 1), (2, 2)):
+            seed = 5000 + idx
+            q, k, v, kc, vc, tm = _verify_inputs(H, Hkv, 64, seed)
+            R = q.shape[1]
+            g = torch.Generator().manual_seed(seed)
+            prefix_lse = (torch.randn(1, H, R, generator=g) * 2 + 3).float()
+            ns = SimpleNamespace(range_indices=torch.arange(1024), K_Cache=kc.clone(), V_Cache=vc.clone(),
+                                 num_heads=H, num_key_value_heads=Hkv, last_layer=last_layer,
+                                 softmax_scale=1 / (128 ** 0.5))
+            cache_lens = torch.tensor([64], dtype=torch.int32)
+            cur, w = llama.LlamaAttention.tree_part_fwd(ns, q, k, v, tm, cache_lens, prefix_lse, 1, R)
+            t = f"c{idx}"
+            arrays.update({f"{t}_H": H, f"{t}_Hkv": Hkv, f"{t}_seed": seed,
+                           f"{t}_in_checksum": np.frombuffer(toy.checksum(q, k, v).encode(), dtype=np.uint8),
+                           f"{t}_mask": tm.to(torch.int8), f"{t}_prefix_lse": prefix_lse,
+                           f"{t}_last_layer": int(last_layer), f"{t}_current_out": cur, f"{t}_weight": w,
+                           f"{t}_kcache_after": ns.K_Cache[:, 64:64 + R], f"{t}_vcache_after": ns.V_Cache[:, 64:64 + R]})
+            idx += 1
+    save("target_tree_part", n_cases=idx, **arrays)
+
+
+def gen_dense_twin(llama, train_llama):
+    """tree_decoding_torch (dense, KV layout [b,Hkv,len,D]) and the hybrid
+    tree_decoding of the test-side LlamaAttention on identical inputs; the
+    attention outputs are captured at the o_proj seam (o_proj = identity)."""
+    arrays = {}
+    idx = 0
+    for (H, Hkv, L) in ((4, 1, 300), (2, 2, 1024), (4, 1, 37)):
+        seed = 6000 + idx
+        q, k, v, kc, vc, tm = _verify_inputs(H, Hkv, L, seed)
+        R = q.shape[1]
+        cache_lens = torch.tensor([L], dtype=torch.int32)
+        ident = lambda x: x
+        t = f"c{idx}"
+        # hybrid path of the reference (flash-attn contract stub + its own tree_part_fwd + fp16 merge)
+        for last_layer in (False, True):
+            ns = SimpleNamespace(range_indices=torch.arange(1024), K_Cache=kc.clone(), V_Cache=vc.clone(),
+                                 num_heads=H, num_key_value_heads=Hkv, head_dim=128, hidden_size=H * 128,
+                                 last_layer=last_layer, softmax_scale=1 / (128 ** 0.5),
+                                 q_proj=lambda x, q=q: q.reshape(1, R, -1), k_proj=lambda x, k=k: k.reshape(1, R, -1),
+                                 v_proj=lambda x, v=v: v.reshape(1, R, -1), o_proj=ident)
+            ns.tree_part_fwd = types.MethodType(llama.LlamaAttention.tree_part_fwd, ns)
+            cos = torch.ones(1, R, 128, dtype=torch.float16)
+            sin = torch.zeros(1, R, 128, dtype=torch.float16)
+            hidden = torch.zeros(1, R, H * 128, dtype=torch.float16)
+            out = llama.LlamaAttention.tree_decoding(ns, hidden, (cos, sin), cache_lens, tm)
+            arrays[f"{t}_hybrid_last{int(last_layer)}"] = out.view(1, R, H, 128)
+        if train_llama is not None:
+            ns = SimpleNamespace(range_indices=torch.arange(1024),
+                                 K_Cache=kc.clone().permute(0, 2, 1, 3).contiguous(),
+                                 V_Cache=vc.clone().permute(0, 2, 1, 3).contiguous(),
+                                 num_heads=H, num_key_value_heads=Hkv, num_key_value_groups=H // Hkv, head_dim=128,
+                                 hidden_size=H * 128, softmax_scale=1 / (128 ** 0.5),
+                                 q_proj=lambda x, q=q: q.reshape(1, R, -1), k_proj=lambda x, k=k: k.reshape(1, R, -1),
+                                 v_proj=lambda x, v=v: v.reshape(1, R, -1), o_proj=ident)
+            cos = torch.ones(1, R, 128, dtype=torch.float16)
+            sin = torch.zeros(1, R, 128, dtype=torch.float16)
+            hidden = torch.zeros(1, R, H * 128, dtype=torch.float16)
+            dense = train_llama.LlamaAttention.tree_decoding_torch(ns, hidden, (cos, sin), cache_lens, tm)
+            arrays[f"{t}_dense"] = dense.view(1, R, H, 128)
+        arrays.update({f"{t}_H": H, f"{t}_Hkv": Hkv, f"{t}_L": L, f"{t}_seed": seed,
+                       f"{t}_in_checksum": np.frombuffer(toy.checksum(q, k, v, kc, vc).encode(), dtype=np.uint8),
+                       f"{t}_mask": tm.to(torch.int8)})
+        idx += 1
+    save("verify_attention", n_cases=idx, have_dense=int(train_llama is not None), **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# G-d: tree_verification
+# --------------------------------------------------------------------------- #
+def gen_tree_verification(llama_glide):
+    rng = np.random.RandomState(77)
+    arrays = {}
+    n = 0
+    shapes = [[4, 16, 16, 16, 16]] * 44 + [[2, 2, 2]] * 6 + [[4, 4]] * 4 + [[1, 1, 1, 1, 1, 1]] * 3 + [[3]] * 3
+    for ci, shape in enumerate(shapes):
+        parents = toy.random_beam_tree(shape, 9000 + ci)
+        mask = toy.tree_mask_from_parents(parents)
+        Fn = mask.shape[0]
+        acc = toy.level_sizes(shape)
+        V = 50
+        spec = rng.randint(2, V, size=Fn).astype(np.int64)
+        pred = rng.randint(2, V, size=Fn).astype(np.int64)
+        mode = ci % 6
+        if mode == 0:      # reject all: root prediction matches no child
+            kids = np.nonzero(parents == 0)[0]
+            pred[0] = V + 1
+        elif mode == 1:    # full-depth accept along a random root-to-leaf path
+            leaf = rng.randint(acc[-2], acc[-1])
+            r = leaf
+            while r != 0:
+                pred[parents[r]] = spec[r]
+                r = parents[r]
+        elif mode == 2:    # partial accept: a path accepted down to a random depth
+            node = rng.randint(1, Fn)
+            r = node
+            while r != 0:
+                pred[parents[r]] = spec[r]
+                r = parents[r]
+            kids = np.nonzero(parents == node)[0]
+            kids = kids[kids != node]
+            if len(kids):
+                pred[node] = V + 2
+        elif mode == 3:    # ties: two sibling paths both fully verified -> the later node index wins
+            for node in rng.randint(1, Fn, size=2):
+                r = node
+                while r != 0:
+                    pred[parents[r]] = spec[r]
+                    spec[np.nonzero(parents == parents[r])[0]] = spec[r]   # duplicate tokens among siblings
+                    r = parents[r]
+        elif mode == 4:    # everything matches everything
+            spec[:] = 7
+            pred[:] = 7
+        # mode 5: pure random
+        Hkv, D = 2, 8
+        L = 11
+        kc = torch.from_numpy(rng.randn(1, L + Fn + 4, Hkv, D).astype(np.float16))
+        vc = torch.from_numpy(rng.randn(1, L + Fn + 4, Hkv, D).astype(np.float16))
+        attn = SimpleNamespace(K_Cache=kc.clone(), V_Cache=vc.clone(), num_key_value_heads=Hkv, head_dim=D)
+        ns = SimpleNamespace(
+            range_tensor=torch.arange(0, 1024)[None, :], reverse_range_tensor=torch.arange(-1024, -32 + 1).unsqueeze(0),
+            oned_range_tensor=torch.arange(0, 1024), diag_matrix=torch.eye(1024, dtype=torch.int64)[None],
+            model=SimpleNamespace(layers=[SimpleNamespace(self_attn=attn)]))
+        cache_lens = torch.tensor([L], dtype=torch.int32)
+        acc_ids, acc_num, double_input = llama_glide.LlamaGlide.tree_verification(
+            ns, torch.from_numpy(spec)[None], torch.from_numpy(pred)[None], torch.from_numpy(mask)[None],
+            cache_lens, non_leaf_len=acc[-2])
+        t = f"c{n}"
+        arrays.update({f"{t}_spec": spec, f"{t}_pred": pred, f"{t}_mask": mask.astype(np.int8), f"{t}_non_leaf_len": acc[-2],
+                       f"{t}_cache_len": L, f"{t}_kc": kc, f"{t}_vc": vc,
+                       f"{t}_acc_ids": acc_ids, f"{t}_acc_num": acc_num, f"{t}_double_input": double_input,
+                       f"{t}_kc_after": attn.K_Cache, f"{t}_vc_after": attn.V_Cache})
+        n += 1
+    # the SURVEY 3.4 worked example
+    save("tree_verification", n_cases=n, **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# G-g: RMSNorm / RoPE from transformers
+# --------------------------------------------------------------------------- #
+def gen_norm_rope():
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
+    arrays = {}
+    # RMSNorm
+    for i, (rows, hd, eps) in enumerate(((74, 1024, 1e-5), (16, 640, 1e-6), (5, 256, 1e-5))):
+        x = toy.randn_f16((1, rows, hd), 7000 + i, scale=1.5)
+        w = (1.0 + 0.1 * torch.randn(hd, generator=torch.Generator().manual_seed(7100 + i))).half()
+        n = LlamaRMSNorm(hd, eps=eps).half()
+        with torch.no_grad():
+            n.weight.copy_(w)
+            y = n(x)
+        arrays.update({f"norm{i}_x": x, f"norm{i}_w": w, f"norm{i}_eps": eps, f"norm{i}_y": y})
+    # RoPE: default theta=283461213 (Llama-3-8B-262k), theta=1e6 (QwQ), linear x4 (Vicuna-16k), linear x8 (LongChat-13B)
+    ropes = [("default", 283461213.0, None, 262144), ("default", 1e6, None, 32768),
+             ("linear", 10000.0, 4.0, 16384), ("linear", 10000.0, 8.0, 16384)]
+    for i, (typ, theta, factor, maxpos) in enumerate(ropes):
+        c = LlamaConfig(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=maxpos)
+        rp = {"rope_theta": theta, "rope_type": typ}
+        if factor is not None:
+            rp["factor"] = factor
+        c.rope_parameters = rp
+        rot = LlamaRotaryEmbedding(config=c)
+        g = torch.Generator().manual_seed(7200 + i)
+        pos = torch.cat([torch.randint(0, maxpos - 1, (1, 60), generator=g),
+                         torch.tensor([[0, 1, maxpos - 1, maxpos // 2, 131072 % maxpos, 16384 % maxpos,
+                                        12345, 54321 % maxpos, 99999 % maxpos, 7, 8, 9, 10, 11]])], dim=1)
+        x = torch.zeros(1, pos.shape[1], 1, dtype=torch.float16)
+        cos, sin = rot(x, pos)
+        q = toy.randn_f16((1, pos.shape[1], 4, 128), 7300 + i)
+        k = toy.randn_f16((1, pos.shape[1], 2, 128), 7400 + i)
+        qe, ke = apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)
+        arrays.update({f"rope{i}_inv_freq": rot.inv_freq.float(), f"rope{i}_scaling": float(rot.attention_scaling),
+                       f"rope{i}_pos": pos, f"rope{i}_cos": cos, f"rope{i}_sin": sin,
+                       f"rope{i}_q": q, f"rope{i}_k": k, f"rope{i}_q_out": qe, f"rope{i}_k_out": ke,
+                       f"rope{i}_theta": theta, f"rope{i}_factor": factor or 1.0})
+    save("norm_rope", n_norm=3, n_rope=len(ropes), **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# G-e / G-f: end-to-end generation traces on toy models
+# --------------------------------------------------------------------------- #
+def gen_generate(llama, llama_glide):
+    arrays = {}
+    runs = [
+        # name, cfg overrides, weight seed, agreement, prompt len, max_gen_len, tree_shape
+        ("rand", {}, 11, 1.0, 300, 40, [4, 16, 16, 16, 16]),
+        ("forced", {}, 12, 0.0, 200, 48, [4, 16, 16, 16, 16]),
+        ("mixed", {}, 13, 0.05, 260, 64, [4, 16, 16, 16, 16]),
+        ("mixed_small_tree", {}, 14, 0.05, 150, 40, [2, 4, 4]),
+        ("gqa_mixed", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 15, 0.05, 130, 40,
+         [4, 16, 16, 16, 16]),
+    ]
+    for name, over, wseed, agree, plen, glen, shape in runs:
+        cfg = toy.toy_config(**over)
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
+        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        install_triton_stubs()      # after model construction
+        ids = toy.make_prompt(cfg, plen, 100 + wseed)
+        pl = torch.tensor([plen])
+        trace = {"tree_mask": [], "all_spec": [], "llm_pred": [], "acc_ids": [], "acc_num": [], "cache_lens": []}
+        orig = m.tree_verification
+
+        def spy(input_ids, output_ids, tree_mask, cache_lens, non_leaf_len, _orig=orig, _tr=trace):
+            _tr["tree_mask"].append(tree_mask.clone())
+            _tr["all_spec"].append(input_ids.clone())
+            _tr["llm_pred"].append(output_ids.clone())
+            _tr["cache_lens"].append(cache_lens.clone())
+            r = _orig(input_ids, output_ids, tree_mask, cache_lens, non_leaf_len=non_leaf_len)
+            ids_pad = torch.full((1, 8), -1, dtype=torch.int64)
+            ids_pad[:, :r[0].shape[1]] = r[0]
+            _tr["acc_ids"].append(ids_pad)
+            _tr["acc_num"].append(r[1].clone())
+            return r
+
+        m.tree_verification = spy
+        with torch.inference_mode():
+            v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=glen)
+            t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=shape, max_gen_len=glen)
+            s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=glen)
+        n_tok = int(t_count) + int(t_num)
+        assert torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]), f"{name}: tree != vanilla"
+        n_s = int(s_count) + int(s_num)
+        n_cmp = min(n_s, glen)
+        assert torch.equal(v_out[0, :n_cmp], s_out[0, :n_cmp]), f"{name}: chain != vanilla"
+        print(f"[{name}] tree: count={int(t_count)} num={int(t_num)} tau={(n_tok) / int(t_num):.2f};"
+              f" chain: count={int(s_count)} num={int(s_num)}")
+        arrays.update({
+            f"{name}_cfg_keys": np.array(sorted(over.keys()), dtype="U32"),
+            f"{name}_cfg_vals": np.array([over[k] for k in sorted(over.keys())], dtype=np.int64),
+            f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
+            f"{name}_tree_shape": np.array(shape), f"{name}_prompt_seed": 100 + wseed,
+            f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
+            f"{name}_prompt": ids,
+            f"{name}_vanilla_out": v_out, f"{name}_vanilla_num": int(v_num),
+            f"{name}_tree_out": t_out, f"{name}_tree_count": int(t_count), f"{name}_tree_num": int(t_num),
+            f"{name}_chain_out": s_out, f"{name}_chain_count": int(s_count), f"{name}_chain_num": int(s_num),
+            f"{name}_tr_tree_mask": torch.cat(trace["tree_mask"], 0).to(torch.int8),
+            f"{name}_tr_all_spec": torch.cat(trace["all_spec"], 0),
+            f"{name}_tr_llm_pred": torch.cat(trace["llm_pred"], 0),
+            f"{name}_tr_acc_ids": torch.cat(trace["acc_ids"], 0),
+            f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
+            f"{name}_tr_cache_lens": torch.cat(trace["cache_lens"], 0),
+        })
+    save("generate", runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# draft-layer seams: GlideAttention.decoding / tree_decoding (attention outputs)
+# --------------------------------------------------------------------------- #
+def gen_draft_attention(llama_glide):
+    """Draft self-attention at the o_proj seam, through the reference's own
+    GlideAttention.decoding / .tree_decoding (real Triton kernel, interpreter)."""
+    arrays = {}
+    idx = 0
+    for (H, Hkv, p) in ((4, 1, 700), (2, 2, 100), (4, 1, 520)):
+        seed = 8000 + idx
+        Lalloc = p + 200
+        kc0 = torch.zeros(1, Lalloc, Hkv, 128, dtype=torch.float16)
+        vc0 = torch.zeros(1, Lalloc, Hkv, 128, dtype=torch.float16)
+        kc0[:, :p] = toy.randn_f16((1, p, Hkv, 128), seed * 11 + 0)
+        vc0[:, :p] = toy.randn_f16((1, p, Hkv, 128), seed * 11 + 1)
+        t = f"c{idx}"
+        arrays.update({f"{t}_H": H, f"{t}_Hkv": Hkv, f"{t}_p": p, f"{t}_seed": seed,
+                       f"{t}_in_checksum": np.frombuffer(toy.checksum(kc0, vc0).encode(), dtype=np.uint8)})
+        ident = lambda x: x
+        cos1 = lambda n: (torch.ones(1, n, 128, dtype=torch.float16), torch.zeros(1, n, 128, dtype=torch.float16))
+
+        def mk_ns(q, k, v, n):
+            return SimpleNamespace(K_Cache=kc.clone(), V_Cache=vc.clone(), num_heads=H, num_key_value_heads=Hkv,
+                                   num_key_value_groups=H // Hkv, head_dim=128, hidden_size=H * 128,
+                                   softmax_scale=1 / (128 ** 0.5), range_indices=torch.arange(1024),
+                                   q_proj=lambda x: q.reshape(1, n, -1), k_proj=lambda x: k.reshape(1, n, -1),
+                                   v_proj=lambda x: v.reshape(1, n, -1), o_proj=ident)
+        # step 0 with a = 3 rows appended at cache_lens = p - 2 (the accepted tokens)
+        a = 3
+        kc, vc = kc0, vc0
+        q = toy.randn_f16((1, a, H, 128), seed * 11 + 2)
+        k = toy.randn_f16((1, a, Hkv, 128), seed * 11 + 3)
+        v = toy.randn_f16((1, a, Hkv, 128), seed * 11 + 4)
+        ns = mk_ns(q, k, v, a)
+        cl = torch.tensor([p - a + 1], dtype=torch.int32)
+        out = llama_glide.GlideAttention.decoding(ns, torch.zeros(1, a, H * 128, dtype=torch.float16), cos1(a), cl, None, None)
+        arrays.update({f"{t}_s0_q": q, f"{t}_s0_k": k, f"{t}_s0_v": v, f"{t}_s0_cache_lens": cl,
+                       f"{t}_s0_out": out.view(1, a, H, 128)})
+        kc, vc = ns.K_Cache, ns.V_Cache            # caches now hold p+1 rows... root at p
+        # tree steps
+        parents = toy.random_beam_tree([4, 16, 16, 16, 16], seed)
+        full = toy.tree_mask_from_parents(parents)
+        for lvl, (M, N) in enumerate(((4, 5), (16, 21), (16, 37), (16, 53))):
+            tm = torch.from_numpy(full[N - M:N, :N].copy()).unsqueeze(0)
+            q = toy.randn_f16((1, M, H, 128), seed * 11 + 10 + lvl * 3)
+            k = toy.randn_f16((1, M, Hkv, 128), seed * 11 + 11 + lvl * 3)
+            v = toy.randn_f16((1, M, Hkv, 128), seed * 11 + 12 + lvl * 3)
+            ns = mk_ns(q, k, v, M)
+            ns.triton_tree_part_fwd = types.MethodType(llama_glide.GlideAttention.triton_tree_part_fwd, ns)
+            cl = torch.tensor([p], dtype=torch.int32)
+            out = llama_glide.GlideAttention.tree_decoding(ns, torch.zeros(1, M, H * 128, dtype=torch.float16), cos1(M),
+                                                           cl, None, None, None, tm)
+            arrays.update({f"{t}_t{lvl}_q": q, f"{t}_t{lvl}_k": k, f"{t}_t{lvl}_v": v, f"{t}_t{lvl}_mask": tm.to(torch.int8),
+                           f"{t}_t{lvl}_out": out.view(1, M, H, 128)})
+            kc, vc = ns.K_Cache, ns.V_Cache
+        idx += 1
+    save("draft_attention", n_cases=idx, **arrays)
+
+
+def main():
+    install_shims()
+    llama, llama_glide, triton_tree_attn, train_llama = import_reference()
+    gen_norm_rope()
+    gen_tree_verification(llama_glide)
+    gen_target_tree_part(llama)
+    gen_dense_twin(llama, train_llama)
+    gen_generate(llama, llama_glide)
+    install_triton_stubs()          # after model construction
+    gen_triton_tree(triton_tree_attn)
+    gen_draft_attention(llama_glide)
+
+
+if __name__ == "__main__":
+    main()
