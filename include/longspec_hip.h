@@ -1,0 +1,163 @@
+/*
+ * longspec_hip.h -- C ABI of liblongspec_hip.so: MI355X (gfx950) kernels for the
+ * draft-then-verify decode round of LongSpec.
+ *
+ * The reference (sail-sg/LongSpec) has no FFI layer of its own; its operator
+ * seams on this path are Python callables.  Each entry point below
+ * replaces one of those seams and cites it (paths relative to the reference
+ * root).  Conventions: extern "C"; raw DEVICE pointers + explicit dims/strides
+ * (in elements); caller-allocated outputs and workspace (size-query functions);
+ * every launch is stream-ordered on `stream` (a hipStream_t passed as void*);
+ * no host synchronisation, no allocation, no hidden global state except the
+ * thread-local last-error string.  Return value: 0 = ok, negative = LS_ERR_*.
+ * Sequence lengths live on the DEVICE (int32), as in the reference
+ * (`cache_seqlens=cache_lens`); `kv_len_hint` is a host-side upper bound used
+ * only to size the launch grid.
+ *
+ * dtype: LS_F16 (the reference hard-codes fp16, longspec/test/llama_glide.py:474)
+ * or LS_BF16.  head_dim must be 128 (longspec/test/llama.py:95).
+ */
+#ifndef LONGSPEC_HIP_H
+#define LONGSPEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_OK 0
+#define LS_ERR_INVALID_ARG (-1)
+#define LS_ERR_UNSUPPORTED (-2)
+#define LS_ERR_WORKSPACE (-3)
+#define LS_ERR_LAUNCH (-4)
+
+#define LS_F16 0
+#define LS_BF16 1
+
+/* how the "new key block" (tree / appended tokens) is computed and merged */
+#define LS_NEW_NONE 0   /* prefix only                                                         */
+#define LS_NEW_FLASH 1  /* flash_attn_with_kvcache(k=,v=) semantics: ONE softmax over prefix+new */
+#define LS_NEW_TARGET 2 /* LlamaAttention.tree_part_fwd + fp16 merge  (llama.py:387,394-421)    */
+#define LS_NEW_DRAFT 3  /* triton_tree_attn._fwd_kernel + fp32 merge  (llama_glide.py:300-329)  */
+
+typedef struct ls_attn_desc {
+    /* tensors (device) */
+    const void* q;      /* [b, sq, H, 128]                     q_stride_{b,s,h}                  */
+    void* k_cache;      /* [b, S, Hkv, 128]  read; written when scatter_new != 0                  */
+    void* v_cache;      /*                                      kc_stride_{b,s,h} (shared by K,V) */
+    const void* k_new;  /* [b, n_new_rows, Hkv, 128] or NULL    kn_stride_{b,s,h}                 */
+    const void* v_new;
+    const int32_t* cache_seqlens; /* [b] valid prefix rows L (device)                             */
+    const uint32_t* mask_bits;    /* [b, sq, mask_words] bit j of row r = new-block key j visible */
+    void* out;          /* [b, sq, H, 128] dtype                out_stride_{b,s,h}                */
+    float* lse;         /* [b, H, sq] fp32 or NULL (LS_NEW_NONE / LS_NEW_FLASH only)              */
+    /* dims */
+    int32_t b, sq, H, Hkv;
+    int32_t dtype;         /* LS_F16 / LS_BF16                                                    */
+    int32_t new_mode;      /* LS_NEW_*                                                            */
+    int32_t n_new;         /* keys in the new block (0 for LS_NEW_NONE)                           */
+    int32_t n_new_cached;  /* leading new-block keys that already sit in the cache at L + j       */
+    int32_t mask_words;    /* uint32 words per mask row (>= ceil(n_new/32))                       */
+    int32_t scatter_new;   /* write k_new/v_new rows into the caches at L + n_new_cached + i      */
+    int32_t causal;        /* prefix: bottom-right causal alignment (flash-attn semantics)        */
+    int32_t window_left;   /* prefix: sliding window to the left, -1 = none                       */
+    int32_t n_app;         /* keys counted as appended for the bottom-right alignment (sk = L+n_app) */
+    int32_t prescale_q;    /* LS_NEW_TARGET: last layer multiplies q by the scale first (G1)      */
+    int32_t kv_len_hint;   /* host upper bound of max(cache_seqlens) -- grid sizing only          */
+    int32_t n_splits;      /* 0 = choose automatically                                            */
+    float softmax_scale;
+    int64_t q_stride_b, q_stride_s, q_stride_h;
+    int64_t kc_stride_b, kc_stride_s, kc_stride_h;
+    int64_t kn_stride_b, kn_stride_s, kn_stride_h;
+    int64_t out_stride_b, out_stride_s, out_stride_h;
+} ls_attn_desc;
+
+/* ---- library ---------------------------------------------------------------- */
+int ls_version(void);
+const char* ls_last_error(void);
+
+/* ---- attention (K1..K7) ------------------------------------------------------- */
+
+/* Bytes of scratch an attention call with this descriptor needs (split-KV partials). */
+size_t ls_attn_workspace_bytes(const ls_attn_desc* d);
+
+/* Number of prefix partials stage 1 writes for this descriptor (splits x key-slices). */
+int ls_attn_num_parts(const ls_attn_desc* d);
+
+/* One fused attention call = stage 1 (split-KV partials + new-block part) then
+ * stage 2 (log-sum-exp combine + reference-order merge), both on `stream`.
+ *  LS_NEW_NONE / LS_NEW_FLASH : flash_attn_with_kvcache as called at
+ *      longspec/test/llama.py:324,385 and llama_glide.py:261,265,297,300
+ *  LS_NEW_TARGET : LlamaAttention.tree_decoding, llama.py:385-387 + tree_part_fwd :394-421
+ *      (prefix flash-decoding + KV scatter + tree-masked part + fp16 merge)   [K1+K2+K3]
+ *  LS_NEW_DRAFT  : GlideAttention.tree_decoding self-attn branch, llama_glide.py:300-302
+ *      + triton_tree_part_fwd :309-329 (window prefix + Triton tree kernel + fp32 merge) [K5+K6] */
+int ls_attn_fwd(const ls_attn_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stage 1 only: writes partials into the workspace (multi-GPU path). */
+int ls_attn_partial(const ls_attn_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Combine this rank's prefix partials into ONE normalised partial for the exchange:
+ * o32 [b,sq,H,128] fp32, lse [b,H,sq] fp32 (the tree part stays in the workspace). */
+int ls_attn_reduce_local(const ls_attn_desc* d, void* workspace, size_t workspace_bytes,
+                         float* o32, float* lse, void* stream);
+
+/* Stage 2 with externally gathered prefix partials (fixed rank order => deterministic):
+ * parts_o [n_parts][b,sq,H,128] fp32, parts_lse [n_parts][b,H,sq]; the new-block part is
+ * taken from `workspace` (written by ls_attn_partial).  N-way generalisation of
+ * llama.py:385-387,420. */
+int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* N-way log-sum-exp merge of normalised partials (no new block): out [b,sq,H,128] dtype
+ * and/or o32 + lse.  Any of out/o32/lse may be NULL. */
+int ls_lse_merge(const float* parts_o, const float* parts_lse, int n_parts, int b, int sq, int H,
+                 int dtype, void* out, float* o32, float* lse, void* stream);
+
+/* tree_mask int64 [b,M,N] (non-zero = visible; llama_glide.py:984,1082-1085) -> packed
+ * uint32 [b,M,words] (bit j%32 of word j/32), zero padded. */
+int ls_pack_tree_mask(const int64_t* tree_mask, int b, int M, int N, uint32_t* bits, int words, void* stream);
+
+/* ---- RMSNorm / RoPE (K8, K9) ------------------------------------------------ */
+
+/* LlamaRMSNorm.forward (transformers; imported at longspec/test/llama.py:36; vendored
+ * longspec/test/qwen2.py:82-87): y = w * dtype(x32 * rsqrt(mean(x32^2)+eps)).
+ * Optional fused residual add: if residual != NULL, x <- x + residual is formed first
+ * (rounded to dtype, as `residual + hidden_states` llama.py:492) and written to sum_out. */
+int ls_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void* y, void* sum_out,
+                   int rows, int hidden, float eps, int dtype, void* stream);
+
+/* LlamaRotaryEmbedding.forward (transformers; vendored qwen2.py:163-178):
+ * cos/sin [rows,128] dtype from int64 positions and fp32 inv_freq[64]. */
+int ls_rope_cos_sin(const int64_t* positions, const float* inv_freq, float attention_scaling,
+                    void* cos, void* sin, int rows, int dtype, void* stream);
+
+/* apply_rotary_pos_emb(q,k,cos,sin,unsqueeze_dim=2) (llama.py:378, llama_glide.py:294), in
+ * place on q [rows,Hq,128] and k [rows,Hk,128] (row strides in elements). */
+int ls_rope_apply(void* q, void* k, const void* cos, const void* sin, int rows, int Hq, int Hk,
+                  int64_t q_row_stride, int64_t k_row_stride, int dtype, void* stream);
+
+/* Tree positions: pos[r] = base[b] + sum_j mask[b,r,j] - 1 (llama.py:575-577, llama_glide.py:1032) */
+int ls_tree_positions(const int64_t* tree_mask, const int32_t* base, int b, int M, int N,
+                      int64_t* positions, void* stream);
+
+/* ---- accept / reject tree collapse (K10) ---------------------------------------- */
+
+/* LlamaGlide.tree_verification (longspec/test/llama_glide.py:1128-1175), b == 1 per call
+ * row: all_spec/all_llm_pred [b,F] int64, tree_mask [b,F,F] int64, cache_lens [b] int32
+ * (already advanced by acc-1, :1104).  Outputs: acc_ids [b,max_acc] int64 (padded with
+ * all_llm_pred entries exactly like the reference's gather), acc_num [b] int64,
+ * double_input [b] int32, index_mapping [b,max_acc] int64.  Moves the LAST target layer's
+ * KV rows cache_lens+index_mapping[j] -> cache_lens+j (j < acc_num) in the same launch. */
+int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const int64_t* tree_mask,
+                     const int32_t* cache_lens, int b, int F, int non_leaf_len, int max_acc,
+                     int64_t* acc_ids, int64_t* acc_num, int32_t* double_input, int64_t* index_mapping,
+                     void* k_cache, void* v_cache, int64_t kc_stride_b, int64_t kc_stride_s,
+                     int row_elems, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LONGSPEC_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of liblongspec_hip.so (the C ABI declared in include/longspec_hip.h).
+
+The library is REQUIRED: there is no CPU or PyTorch fallback for any operator on
+the hot path.  Import errors are raised loudly, with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "liblongspec_hip.so")
+
+LS_F16, LS_BF16 = 0, 1
+LS_NEW_NONE, LS_NEW_FLASH, LS_NEW_TARGET, LS_NEW_DRAFT = 0, 1, 2, 3
+
+
+class AttnDesc(C.Structure):
+    """Mirror of ``ls_attn_desc`` (include/longspec_hip.h) -- keep field order in sync."""
+    _fields_ = [
+        ("q", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p),
+        ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("cache_seqlens", C.c_void_p),
+        ("mask_bits", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p),
+        ("b", C.c_int32), ("sq", C.c_int32), ("H", C.c_int32), ("Hkv", C.c_int32),
+        ("dtype", C.c_int32), ("new_mode", C.c_int32), ("n_new", C.c_int32), ("n_new_cached", C.c_int32),
+        ("mask_words", C.c_int32), ("scatter_new", C.c_int32), ("causal", C.c_int32), ("window_left", C.c_int32),
+        ("n_app", C.c_int32), ("prescale_q", C.c_int32), ("kv_len_hint", C.c_int32), ("n_splits", C.c_int32),
+        ("softmax_scale", C.c_float),
+        ("q_stride_b", C.c_int64), ("q_stride_s", C.c_int64), ("q_stride_h", C.c_int64),
+        ("kc_stride_b", C.c_int64), ("kc_stride_s", C.c_int64), ("kc_stride_h", C.c_int64),
+        ("kn_stride_b", C.c_int64), ("kn_stride_s", C.c_int64), ("kn_stride_h", C.c_int64),
+        ("out_stride_b", C.c_int64), ("out_stride_s", C.c_int64), ("out_stride_h", C.c_int64),
+    ]
+
+
+# every symbol include/longspec_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+SYMBOLS = {
+    "ls_version": (C.c_int, []),
+    "ls_last_error": (C.c_char_p, []),
+    "ls_attn_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
+    "ls_attn_num_parts": (C.c_int, [C.POINTER(AttnDesc)]),
+    "ls_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
+    "ls_attn_partial": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
+    "ls_attn_reduce_local": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P, _P]),
+    "ls_attn_finish": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _I, _P, C.c_size_t, _P]),
+    "ls_lse_merge": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ls_pack_tree_mask": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
+    "ls_rmsnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P]),
+    "ls_rope_cos_sin": (C.c_int, [_P, _P, C.c_float, _P, _P, _I, _I, _P]),
+    "ls_rope_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _L, _L, _I, _P]),
+    "ls_tree_positions": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    "ls_tree_collapse": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
+}
+
+
+class LongSpecHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension is required (no CPU/PyTorch fallback exists). "
+            "Build it with `python -m longspec_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)           # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ls_last_error()
+        raise LongSpecHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,892 @@
+// Hybrid tree-verification / draft-step attention for gfx950 (CDNA4).
+//
+// Stage 1  attn_partial_kernel : split-KV "flash-decoding" over the long prefix KV
+//          (one workgroup per (kv head, key split)), plus one workgroup per kv head
+//          for the "new key block" (the 74 tree tokens of a verify pass / the tree
+//          levels of a draft step / appended decode tokens) under a bit mask.
+// Stage 2  attn_finish_kernel  : log-sum-exp combine of the split partials and the
+//          reference-order merge with the new-block part.
+//
+// Reference seams replaced (paths relative to the reference root):
+//   flash_attn_with_kvcache       longspec/test/llama.py:324,385  llama_glide.py:261,265,297,300
+//   LlamaAttention.tree_part_fwd  longspec/test/llama.py:394-421   (+ merge :387)
+//   triton_tree_attn._fwd_kernel  longspec/test/triton_tree_attn.py:115-251 (+ merge llama_glide.py:302)
+//
+// MI355X mapping.  All g = H/Hkv query heads of a kv head and all sq query rows are
+// packed into one M = g*sq row block that shares every K/V byte read from HBM (GQA-4,
+// 74 rows: 296 flop per KV byte, i.e. right at the MFMA/HBM ridge).  A workgroup is
+// 4 waves = one wave per SIMD with the whole 512-entry register file: each wave owns
+// QT tiles of 16 rows and computes, per 32-key block,
+//     S^T[key][row] = K . Q^T          (mfma_f32_16x16x32: A = K fragment,  B = Q^T fragment)
+//     O^T[d][row]  += V^T . P^T        (A = V^T via ds_read_b64_tr_b16,     B = P^T = S^T's own layout)
+// Both products are "transposed" so that a lane always owns ONE query row (lane&15):
+// the soft-max running max / sum / rescale are per-lane scalars (two xor-shuffles per
+// row for the max), P feeds the second MFMA straight from registers, and nothing but
+// K/V tiles ever goes through LDS.  K/V tiles go HBM -> LDS directly (global_load_lds,
+// 16 bytes per lane, 256 contiguous bytes per key and kv head, no staging registers)
+// into a double buffer: the DMA of tile t+1 is in flight while tile t is multiplied,
+// one barrier per tile.  The LDS image is XOR-swizzled (applied on the per-lane SOURCE
+// address, the LDS destination of the DMA being lane-linear) so that both the
+// ds_read_b128 K-fragment reads and the transposing V reads are bank-conflict free.
+#include "ls_common.h"
+
+namespace {
+
+constexpr int D = LS_HEAD_DIM;      // 128
+constexpr int ROWB = D * 2;         // bytes per key row (fp16/bf16)
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnK {
+    const void* q;
+    const void* k_cache;
+    const void* v_cache;
+    void* k_cache_w;
+    void* v_cache_w;
+    const void* k_new;
+    const void* v_new;
+    const int32_t* cache_seqlens;
+    const uint32_t* mask_bits;
+    float* parts_o;    // [n_parts][b][sq][H][D]
+    float* parts_lse;  // [n_parts][b][H][sq]
+    float* new_o;      // [b][sq][H][D]
+    float* new_lse;    // [b][H][sq]
+    int b, sq, H, Hkv, g, M;
+    int has_new, new_mode, n_new, n_new_cached, mask_words, scatter_new, prescale_q;
+    int causal, window_left, n_app;
+    int n_splits, row_chunks, rows_per_chunk;
+    float scale;
+    long q_sb, q_ss, q_sh;
+    long kc_sb, kc_ss, kc_sh;
+    long kn_sb, kn_ss, kn_sh;
+};
+
+template <typename E, int QT>
+struct WaveAcc {
+    f32x4 acc[8][QT];   // O^T[d-tile][q-tile]: lane holds d = dt*16 + g4*4 + reg for row l15
+    float m[QT];        // running max (raw score units)
+    float l[QT];        // running sum of exp (this lane's keys only)
+};
+
+// ---- LDS tile layout -------------------------------------------------------------
+// K (and the per-wave Q image): row-major [row][128], 16-byte slot s stored at slot s ^ (row & 15)
+// V: row-major [key][128], 16-byte slot s stored at slot s ^ ((key & 7) << 1)
+// All fragment addresses are  <per-lane table entry> + <wave-uniform base> + <immediate>:
+//   ktbl[k4] = l15*256 + (((k4*4 + g4) ^ l15) << 4)            rows 16-aligned => (row & 15) == l15
+//   vtbl[dt] = (g4*4 + l15/4)*256 + (((dt*2 + (l15&3)/2) ^ ((key & 7) << 1)) << 4) + (l15&1)*8
+// so the hot loop carries 12 address registers instead of one per (buffer, block, fragment).
+struct LaneTbl {
+    int k[4];
+    int v[8];
+};
+
+__device__ __forceinline__ LaneTbl make_lane_tbl(int l15, int g4) {
+    LaneTbl t;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) t.k[k4] = l15 * ROWB + (((k4 * 4 + g4) ^ l15) << 4);
+    const int key = g4 * 4 + (l15 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+        t.v[dt] = key * ROWB + (((dt * 2 + ((l15 & 3) >> 1)) ^ ((key & 7) << 1)) << 4) + ((l15 & 1) << 3);
+    return t;
+}
+
+template <typename V8>
+__device__ __forceinline__ V8 lds_read16(unsigned addr) {
+    typedef __attribute__((address_space(3))) V8 lds_v8;
+    return *(lds_v8*)(uintptr_t)addr;
+}
+
+// S^T for one 32-key block: s[kt][qt], kt = 16-key tile.  kbase = LDS byte address of the
+// block's first key row; qbase = LDS byte address of this wave's Q image (QLDS) -- when the
+// 160 accumulator registers of QT >= 5 leave no room for the 80 registers of Q^T fragments
+// they are re-read from LDS (ds_read_b128, same swizzle as K) instead of being spilled.
+template <typename E, int QT, bool QLDS>
+__device__ __forceinline__ void qk_block(f32x4 (&s)[2][QT], const typename E::V8 (&qf)[QLDS ? 1 : QT][4],
+                                         const LaneTbl& tb, unsigned qbase, unsigned kbase) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const unsigned ka = kbase + tb.k[k4];
+        typename E::V8 kf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[kt] = lds_read16<typename E::V8>(ka + kt * 16 * ROWB);
+        const unsigned qa = qbase + tb.k[k4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            typename E::V8 qv;
+            if (QLDS)
+                qv = lds_read16<typename E::V8>(qa + qt * 16 * ROWB);
+            else
+                qv = qf[QLDS ? 0 : qt][k4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[kt], qv, s[kt][qt]);
+        }
+    }
+}
+
+// O^T += V^T . P^T for one 32-key block.  pf[qt] = 8 probabilities of row l15:
+// elements 0..3 = keys g4*4 + e, elements 4..7 = keys 16 + g4*4 + e of the block
+// (exactly the S^T accumulator layout of the two 16-key tiles).  The A operand V^T
+// [16 d x 32 keys] comes from two transposing LDS reads: within a 16-lane group, lane p
+// supplies the address of V[key0 + p/4][d0 + (p%4)*4 .. +3] and receives V[key0 + j][d0 + p],
+// j = 0..3 (ds_read_b64_tr_b16).
+template <typename E, int QT>
+__device__ __forceinline__ void pv_block(WaveAcc<E, QT>& w, const typename E::V8 (&pf)[QT], const LaneTbl& tb,
+                                         unsigned vbase) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+        const unsigned va = vbase + tb.v[dt];
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
+        union {
+            struct { s16x4 a, b; } s;
+            typename E::V8 v;
+        } u;
+        u.s.a = lo;
+        u.s.b = hi;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) w.acc[dt][qt] = E::mfma(u.v, pf[qt], w.acc[dt][qt]);
+    }
+}
+
+// Online soft-max update (base-2 exponentials) for one 32-key block whose masked scores are
+// already -inf, then P.V.
+template <typename E, int QT>
+__device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], float c, const LaneTbl& tb,
+                                             unsigned vbase) {
+    typename E::V8 pf[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                         fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+        mx = wave_xor_max_16_32(mx);
+        const float m_new = fmaxf(w.m[qt], mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;     // row with no visible key so far
+        if (__any(m_new > w.m[qt])) {
+            const float alpha = __builtin_amdgcn_exp2f((w.m[qt] - m_safe) * c);
+            w.l[qt] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] *= alpha;
+            w.m[qt] = m_new;
+        }
+        const float mc = m_safe * c;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                ps += pe;
+                pf[qt][kt * 4 + e] = E::from_f32(pe);
+            }
+        w.l[qt] += ps;
+    }
+    pv_block<E, QT>(w, pf, tb, vbase);
+}
+
+// ---- HBM -> LDS tile DMA -----------------------------------------------------------------
+// One wave-instruction moves 64 x 16 B = 4 key rows.  LDS slot `pos` of row `key` receives
+// global chunk pos ^ swz(key) (the swizzle is an involution, so the same XOR is used on reads).
+typedef __attribute__((address_space(1))) const void gmem_cv;
+typedef __attribute__((address_space(3))) void lds_v;
+
+template <int TILE, typename F>
+__device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, F&& row_ptr) {
+    const int kq = lane >> 4, pos = lane & 15;
+#pragma unroll
+    for (int i = 0; i < TILE / 16; ++i) {
+        const int grp = i * 4 + wave;
+        const int key = grp * 4 + kq;
+        const char* kp;
+        const char* vp;
+        row_ptr(key, kp, vp);
+        __builtin_amdgcn_global_load_lds((gmem_cv*)(kp + ((pos ^ (key & 15)) << 4)), (lds_v*)(ldsK + grp * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gmem_cv*)(vp + ((pos ^ ((key & 7) << 1)) << 4)), (lds_v*)(ldsV + grp * 1024), 16, 0, 0);
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------
+template <typename E, int RB, int KS, int QT, int TKW>
+__global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
+    constexpr int TILE = KS * TKW;            // keys per workgroup iteration
+    constexpr int BUF = 2 * TILE * ROWB;      // bytes of one (K,V) buffer
+    constexpr bool QLDS = QT >= 5;            // Q^T fragments in LDS instead of registers
+    static_assert(RB * KS == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [2 x (K tile, V tile)] [per-wave Q image (QLDS only)]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave / KS, ks = wave % KS;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bi = blockIdx.z;
+    const int kvh = blockIdx.y % p.Hkv;
+    const int chunk = blockIdx.y / p.Hkv;
+    const bool is_new = p.has_new && blockIdx.x == 0;
+    const int split = (int)blockIdx.x - p.has_new;
+    const int L = p.cache_seqlens[bi];
+    const float c = p.scale * LOG2E;
+    const int sk = L + p.n_app;
+
+    // ---- rows of this wave: lane l15 of q-tile qt owns row m = row0 + qt*16 + l15 -----------
+    const int row0 = chunk * p.rows_per_chunk + rb * QT * 16;
+    int rrow[QT];                 // query row r in [0,sq) (0 for padding rows: computed, never stored)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = row0 + qt * 16 + l15;
+        rrow[qt] = m < p.M ? m % p.sq : 0;
+    }
+    // visible prefix key range of row r (flash-attn bottom-right alignment):
+    //   lo(r) = max(0, r + sk - sq - window_left), hi(r) = min(L, r + sk - sq + 1) if causal else L
+    int lo_min = 0, lo_max = 0, hi_min = L, hi_max = L;
+    if (p.window_left >= 0) {
+        lo_min = max(0, sk - p.sq - p.window_left);
+        lo_max = max(0, sk - 1 - p.window_left);
+    }
+    if (p.causal) {
+        hi_min = max(0, min(L, sk - p.sq + 1));
+        hi_max = max(0, min(L, sk));
+    }
+
+    // ---- Q^T fragments (B operand of the first product) ------------------------------
+    typename E::V8 qf[QLDS ? 1 : QT][4];
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;          // LDS byte address of the carve
+    const unsigned qbase = smem_a + 2 * BUF + wave * (QT * 16 * ROWB);
+    const LaneTbl tb = make_lane_tbl(l15, g4);
+    const bool prescale = is_new && p.new_mode == LS_NEW_TARGET && p.prescale_q;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = row0 + qt * 16 + l15;
+        const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
+        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb +
+                                  (long)rrow[qt] * p.q_ss + (long)head * p.q_sh + g4 * 8;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            typename E::V8 v = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+            if (prescale) {   // `query_states * self.softmax_scale` in the activation dtype (llama.py:407)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
+            }
+            if (QLDS)
+                *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(qbase + qt * 16 * ROWB + tb.k[k4]) = v;
+            else
+                qf[QLDS ? 0 : qt][k4] = v;
+        }
+    }
+    // (QLDS: each wave reads back only what it wrote itself; the first __syncthreads() of the
+    //  tile loop orders the ds_write before any ds_read)
+
+    WaveAcc<E, QT> w;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        w.m[qt] = -INFINITY;
+        w.l[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const long kc_row = p.kc_ss * 2;
+
+    if (!is_new) {
+        // ================= prefix split: tiles [t_begin, t_end) of TILE keys =================
+        const int t0 = lo_min / TILE;
+        const int t1 = (hi_max + TILE - 1) / TILE;
+        const int tps = (max(t1 - t0, 0) + p.n_splits - 1) / p.n_splits;
+        const int t_begin = t0 + split * tps;
+        const int t_end = min(t_begin + tps, t1);
+        const int last_key = hi_max - 1;
+        auto dma = [&](int tile, int buf) {
+            char* bK = smem + buf * BUF;
+            tile_dma<TILE>(bK, bK + TILE * ROWB, wave, lane, [&](int key, const char*& kp, const char*& vp) {
+                const long ka = min(tile * TILE + key, last_key);   // tail rows: re-read the last valid key (masked below)
+                kp = kc_base + ka * kc_row;
+                vp = vc_base + ka * kc_row;
+            });
+        };
+        if (t_begin < t_end) dma(t_begin, 0);
+        for (int t = t_begin; t < t_end; ++t) {
+            const int buf = (t - t_begin) & 1;
+            __syncthreads();                      // tile t landed (vmcnt(0) + barrier); buffer buf^1 is free
+            if (t + 1 < t_end) dma(t + 1, buf ^ 1);
+            const unsigned kb_a = smem_a + buf * BUF;               // K tile, V tile follows at + TILE*ROWB
+#pragma unroll 1
+            for (int blk = 0; blk < TKW / 32; ++blk) {
+                const int krow0 = ks * TKW + blk * 32;
+                const int ka0 = t * TILE + krow0;
+                if (ka0 >= hi_max || ka0 + 32 <= lo_min) continue;   // wave-uniform
+                f32x4 s[2][QT];
+                qk_block<E, QT, QLDS>(s, qf, tb, qbase, kb_a + krow0 * ROWB);
+                if (!(ka0 >= lo_max && ka0 + 32 <= hi_min)) {        // block touches a range edge
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const int lo = p.window_left >= 0 ? max(0, rrow[qt] + sk - p.sq - p.window_left) : 0;
+                        const int hi = p.causal ? min(L, rrow[qt] + sk - p.sq + 1) : L;
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int ka = ka0 + kt * 16 + g4 * 4 + e;
+                                if (ka < lo || ka >= hi) s[kt][qt][e] = -INFINITY;
+                            }
+                    }
+                }
+                online_block<E, QT>(w, s, c, tb, kb_a + (TILE + krow0) * ROWB);
+            }
+        }
+        // ---- write the (normalised) partial ------------------------------------------
+        const int part = split * KS + ks;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float lt = wave_xor_sum_16_32(w.l[qt]);
+            const float inv = lt > 0.f ? 1.f / lt : 0.f;
+            const float lse = lt > 0.f ? w.m[qt] * p.scale + __logf(lt) : -INFINITY;
+            const int m = row0 + qt * 16 + l15;
+            if (m < p.M) {
+                const int head = kvh * p.g + m / p.sq;
+                float* op = p.parts_o + ((((long)part * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = w.acc[dt][qt] * inv;
+                if (g4 == 0) p.parts_lse[(((long)part * p.b + bi) * p.H + head) * p.sq + rrow[qt]] = lse;
+            }
+        }
+        return;
+    }
+
+    // ===================== new key block (tree / appended tokens) ===========================
+    const int n_new = p.n_new;
+    const int nblk = (n_new + 31) / 32;
+    const char* kn_base = reinterpret_cast<const char*>(p.k_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
+    const char* vn_base = reinterpret_cast<const char*>(p.v_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
+    const long kn_row = p.kn_ss * 2;
+
+    // scatter the new K/V rows into the caches (llama.py:396-399, llama_glide.py:312-315)
+    if (p.scatter_new && chunk == 0) {
+        char* kw = reinterpret_cast<char*>(p.k_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+        char* vw = reinterpret_cast<char*>(p.v_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+        const int n_rows = n_new - p.n_new_cached;
+        for (int idx = tid; idx < n_rows * 16; idx += 256) {
+            const int i = idx >> 4, ch = idx & 15;
+            const long dst = (long)(L + p.n_new_cached + i) * kc_row;
+            reinterpret_cast<uint4*>(kw + dst)[ch] = reinterpret_cast<const uint4*>(kn_base + (long)i * kn_row)[ch];
+            reinterpret_cast<uint4*>(vw + dst)[ch] = reinterpret_cast<const uint4*>(vn_base + (long)i * kn_row)[ch];
+        }
+    }
+
+    const bool worker = (ks == 0);   // the few new keys are not split across waves
+    const int npass = (p.new_mode == LS_NEW_TARGET) ? 3 : 1;
+    float tmax[QT], tsum[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        tmax[qt] = -INFINITY;
+        tsum[qt] = 0.f;
+    }
+    char* ldsK = smem;
+    char* ldsV = smem + TILE * ROWB;
+    for (int pass = 0; pass < npass; ++pass) {
+        for (int j0 = 0; j0 < nblk * 32; j0 += TILE) {
+            __syncthreads();       // previous tile fully consumed
+            tile_dma<TILE>(ldsK, ldsV, wave, lane, [&](int key, const char*& kp, const char*& vp) {
+                const int j = min(j0 + key, n_new - 1);            // tail rows: masked by zero bits
+                if (j < p.n_new_cached) {
+                    kp = kc_base + (long)(L + j) * kc_row;
+                    vp = vc_base + (long)(L + j) * kc_row;
+                } else {
+                    kp = kn_base + (long)(j - p.n_new_cached) * kn_row;
+                    vp = vn_base + (long)(j - p.n_new_cached) * kn_row;
+                }
+            });
+            __syncthreads();       // tile landed
+            if (!worker) continue;
+#pragma unroll 1
+            for (int krow0 = 0; krow0 < TILE; krow0 += 32) {
+                if (j0 + krow0 >= nblk * 32) break;
+                const int blk = (j0 + krow0) >> 5;
+                uint32_t bits[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int m = row0 + qt * 16 + l15;
+                    bits[qt] = m < p.M ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + blk] : 0u;
+                }
+                f32x4 s[2][QT];
+                qk_block<E, QT, QLDS>(s, qf, tb, qbase, smem_a + krow0 * ROWB);
+                if (p.new_mode != LS_NEW_TARGET) {
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u)) s[kt][qt][e] = -INFINITY;
+                    online_block<E, QT>(w, s, c, tb, smem_a + (TILE + krow0) * ROWB);
+                    continue;
+                }
+                // ---- LlamaAttention.tree_part_fwd numerics (llama.py:406-415): the QK^T result is
+                // rounded to the activation dtype, scaled before (last layer, G1) or after the
+                // product, soft-max in fp32, probabilities rounded before P.V (G2).  Three passes
+                // over the (tiny) block: row max, row sum, then P.V.
+                typename E::V8 pf[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float sv[8];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = round_to<E>(s[kt][qt][e]);
+                            if (!p.prescale_q) x = round_to<E>(x * p.scale);
+                            sv[kt * 4 + e] = ((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u) ? x : -INFINITY;
+                        }
+                    if (pass == 0) {
+                        float mx = sv[0];
+#pragma unroll
+                        for (int e = 1; e < 8; ++e) mx = fmaxf(mx, sv[e]);
+                        tmax[qt] = fmaxf(tmax[qt], wave_xor_max_16_32(mx));
+                    } else {
+                        const float mref = tmax[qt] == -INFINITY ? 0.f : tmax[qt];
+                        float ps = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            sv[e] = expf(sv[e] - mref);
+                            ps += sv[e];
+                        }
+                        if (pass == 1) {
+                            tsum[qt] += ps;
+                        } else {
+                            const float den = tsum[qt] > 0.f ? tsum[qt] : 1.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pf[qt][e] = E::from_f32(sv[e] / den);
+                        }
+                    }
+                }
+                if (pass == 2) pv_block<E, QT>(w, pf, tb, smem_a + (TILE + krow0) * ROWB);
+            }
+        }
+        if (p.new_mode == LS_NEW_TARGET && pass == 1) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) tsum[qt] = wave_xor_sum_16_32(tsum[qt]);
+        }
+    }
+    if (!worker) return;
+
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float scale_o, lse;
+        bool round_o;
+        if (p.new_mode == LS_NEW_TARGET) {
+            scale_o = 1.f;
+            round_o = true;                                                        // fp16 matmul result (llama.py:414)
+            lse = tsum[qt] > 0.f ? tmax[qt] + logf(tsum[qt]) : -INFINITY;        // logsumexp (llama.py:415)
+        } else {
+            const float lt = wave_xor_sum_16_32(w.l[qt]);
+            scale_o = lt > 0.f ? 1.0f / lt : 0.f;              // acc * (1/l)   (triton_tree_attn.py:242)
+            round_o = p.new_mode == LS_NEW_DRAFT;              // o stored in fp16 (triton_tree_attn.py:248)
+            lse = lt > 0.f ? w.m[qt] * p.scale + logf(lt) : -INFINITY;            // m*scale + ln(l) (:243)
+        }
+        const int m = row0 + qt * 16 + l15;
+        if (m < p.M) {
+            const int head = kvh * p.g + m / p.sq;
+            float* op = p.new_o + (((long)bi * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                f32x4 o = w.acc[dt][qt] * scale_o;
+                if (round_o) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = round_to<E>(o[e]);
+                }
+                *reinterpret_cast<f32x4*>(op + dt * 16) = o;
+            }
+            if (g4 == 0) p.new_lse[((long)bi * p.H + head) * p.sq + rrow[qt]] = lse;
+        }
+    }
+}
+
+// ---- stage 2: combine + merge ----------------------------------------------------------
+struct FinK {
+    const float* parts_o;    // [n_parts][b][sq][H][D]
+    const float* parts_lse;  // [n_parts][b][H][sq]
+    const float* new_o;      // [b][sq][H][D] or null
+    const float* new_lse;
+    void* out;               // dtype [b,sq,H,D] (strided) or null
+    float* o32;              // fp32 [b][sq][H][D] or null
+    float* lse_out;          // [b][H][sq] or null
+    int n_parts, b, sq, H, mode;   // mode = LS_NEW_*
+    long out_sb, out_ss, out_sh;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename E>
+__global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * 8 + (tid >> 5);
+    const int h = blockIdx.y, bi = blockIdx.z;
+    const int d = (tid & 31) * 4;
+    if (r >= p.sq) return;
+    const long lse_idx = ((long)bi * p.H + h) * p.sq + r;
+    const long o_idx = (((long)bi * p.sq + r) * p.H + h) * D + d;
+    const long part_lse_stride = (long)p.b * p.H * p.sq;
+    const long part_o_stride = (long)p.b * p.sq * p.H * D;
+    const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
+
+    float mx = -INFINITY;
+    for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, p.parts_lse[i * part_lse_stride + lse_idx]);
+    float lnew = -INFINITY;
+    if (p.new_o != nullptr) lnew = p.new_lse[lse_idx];
+    if (joint) mx = fmaxf(mx, lnew);
+    const float mref = mx == -INFINITY ? 0.f : mx;
+    float den = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < p.n_parts; ++i) {
+        const float l = p.parts_lse[i * part_lse_stride + lse_idx];
+        if (l == -INFINITY) continue;
+        const float wgt = expf(l - mref);
+        den += wgt;
+        o += *reinterpret_cast<const f32x4*>(p.parts_o + i * part_o_stride + o_idx) * wgt;
+    }
+    if (joint && lnew != -INFINITY) {
+        const float wgt = expf(lnew - mref);
+        den += wgt;
+        o += *reinterpret_cast<const f32x4*>(p.new_o + o_idx) * wgt;
+    }
+    float lse = -INFINITY;
+    if (den > 0.f) {
+        o = o / den;
+        lse = mref + logf(den);
+    }
+    if (p.o32) *reinterpret_cast<f32x4*>(p.o32 + o_idx) = o;
+    if (p.lse_out && (tid & 31) == 0) p.lse_out[lse_idx] = lse;
+    if (!p.out) return;
+
+    float res[4];
+    if (p.mode == LS_NEW_TARGET) {
+        // prefix_o * weight + current_out * (1 - weight), every operand and result in the
+        // activation dtype (llama.py:387; weight -> fp16 :420)
+        const f32x4 cur = *reinterpret_cast<const f32x4*>(p.new_o + o_idx);
+        const float wt = round_to<E>(sigmoidf_(lse - lnew));
+        const float omw = round_to<E>(1.0f - wt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = round_to<E>(round_to<E>(o[e]) * wt);
+            const float bb = round_to<E>(cur[e] * omw);
+            res[e] = a + bb;
+        }
+    } else if (p.mode == LS_NEW_DRAFT) {
+        // prefix_o.float() * weight + current_out * (1 - weight) in fp32 (llama_glide.py:302,326)
+        const f32x4 cur = *reinterpret_cast<const f32x4*>(p.new_o + o_idx);
+        const float wt = sigmoidf_(lse - lnew);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res[e] = round_to<E>(o[e]) * wt + cur[e] * (1.0f - wt);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res[e] = o[e];
+    }
+    typename E::V4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = E::from_f32(res[e]);
+    typename E::T* op = reinterpret_cast<typename E::T*>(p.out) + (long)bi * p.out_sb + (long)r * p.out_ss +
+                        (long)h * p.out_sh + d;
+    *reinterpret_cast<typename E::V4*>(op) = ov;
+}
+
+__global__ void pack_mask_kernel(const int64_t* mask, int M, int N, uint32_t* bits, int words, int total_rows) {
+    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    const int64_t* mr = mask + (long)row * N;
+    for (int wd = 0; wd < words; wd += 2) {
+        const int j = wd * 32 + lane;
+        const bool v = (j < N) && (mr[j] != 0);
+        const unsigned long long bal = __ballot(v);
+        if (lane == 0) {
+            bits[(long)row * words + wd] = (uint32_t)bal;
+            if (wd + 1 < words) bits[(long)row * words + wd + 1] = (uint32_t)(bal >> 32);
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+struct Cfg {
+    int RB, KS, QT, TKW, row_chunks, rows_per_chunk;
+};
+
+Cfg pick_cfg(int M) {
+    Cfg c;
+    c.row_chunks = 1;
+    if (M <= 80) {
+        c = Cfg{1, 4, (M + 15) / 16, 32, 1, 0};
+    } else if (M <= 160) {
+        c = Cfg{2, 2, 5, 32, 1, 0};
+    } else if (M <= 320) {
+        c = Cfg{4, 1, 5, 64, 1, 0};
+    } else if (M <= 384) {
+        c = Cfg{4, 1, 6, 64, 1, 0};
+    } else {
+        c = Cfg{4, 1, 5, 64, (M + 319) / 320, 0};
+    }
+    c.rows_per_chunk = c.RB * c.QT * 16;
+    return c;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+int pick_splits(const ls_attn_desc* d, const Cfg& c) {
+    if (d->n_splits > 0) return d->n_splits;
+    const int tile = c.KS * c.TKW;
+    int span = d->kv_len_hint;
+    if (d->window_left >= 0) span = span < d->window_left + d->sq + 1 ? span : d->window_left + d->sq + 1;
+    int tiles = (span + tile - 1) / tile + (d->window_left >= 0 ? 1 : 0);
+    if (tiles < 1) tiles = 1;
+    const int wg_per_split = d->Hkv * c.row_chunks * d->b;
+    int target = num_cus() / wg_per_split;
+    if (target < 1) target = 1;
+    int s = target < tiles ? target : tiles;
+    if (s > 512) s = 512;
+    return s;
+}
+
+struct WsLayout {
+    size_t parts_o, parts_lse, new_o, new_lse, total;
+    int n_parts;
+};
+
+WsLayout ws_layout(const ls_attn_desc* d, const Cfg& c, int n_splits) {
+    WsLayout w;
+    w.n_parts = n_splits * c.KS;
+    const size_t rows = (size_t)d->b * d->sq * d->H;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    w.parts_o = take((size_t)w.n_parts * rows * D * 4);
+    w.parts_lse = take((size_t)w.n_parts * rows * 4);
+    w.new_o = take(rows * D * 4);
+    w.new_lse = take(rows * 4);
+    w.total = off;
+    return w;
+}
+
+int validate(const ls_attn_desc* d) {
+    if (!d) LS_FAIL(LS_ERR_INVALID_ARG, "null descriptor");
+    if (d->b < 1 || d->sq < 1 || d->H < 1 || d->Hkv < 1 || d->H % d->Hkv != 0)
+        LS_FAIL(LS_ERR_INVALID_ARG, "bad dims b=%d sq=%d H=%d Hkv=%d", d->b, d->sq, d->H, d->Hkv);
+    if (d->dtype != LS_F16 && d->dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", d->dtype);
+    if (d->new_mode < LS_NEW_NONE || d->new_mode > LS_NEW_DRAFT) LS_FAIL(LS_ERR_INVALID_ARG, "new_mode %d", d->new_mode);
+    if (d->new_mode != LS_NEW_NONE) {
+        if (d->n_new < 1 || !d->mask_bits || d->mask_words * 32 < d->n_new || d->n_new_cached < 0 ||
+            d->n_new_cached > d->n_new)
+            LS_FAIL(LS_ERR_INVALID_ARG, "new block: n_new=%d cached=%d mask_words=%d", d->n_new, d->n_new_cached, d->mask_words);
+        if (d->n_new_cached < d->n_new && (!d->k_new || !d->v_new)) LS_FAIL(LS_ERR_INVALID_ARG, "k_new/v_new missing");
+    }
+    if (!d->q || !d->k_cache || !d->v_cache || !d->cache_seqlens) LS_FAIL(LS_ERR_INVALID_ARG, "null tensor");
+    if (d->kv_len_hint < 0) LS_FAIL(LS_ERR_INVALID_ARG, "kv_len_hint < 0");
+    if ((d->q_stride_s | d->q_stride_h | d->kc_stride_s | d->kc_stride_h) & 7)
+        LS_FAIL(LS_ERR_INVALID_ARG, "row strides must be multiples of 8 elements (16-byte vector loads)");
+    return LS_OK;
+}
+
+template <typename E, int RB, int KS, int QT, int TKW>
+int launch_partial(const AttnK& k, dim3 grid, hipStream_t s) {
+    constexpr int TILE = KS * TKW;
+    const int lds = 2 * (2 * TILE * ROWB)                 // double-buffered (K,V) tiles
+                    + (QT >= 5 ? 4 * QT * 16 * ROWB : 0);  // per-wave Q image
+    auto fn = attn_partial_kernel<E, RB, KS, QT, TKW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
+    LS_CHECK_LAUNCH("attn_partial_kernel");
+    return LS_OK;
+}
+
+template <typename E>
+int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+    if (c.RB == 1 && c.KS == 4) {
+        switch (c.QT) {
+            case 1: return launch_partial<E, 1, 4, 1, 32>(k, grid, s);
+            case 2: return launch_partial<E, 1, 4, 2, 32>(k, grid, s);
+            case 3: return launch_partial<E, 1, 4, 3, 32>(k, grid, s);
+            case 4: return launch_partial<E, 1, 4, 4, 32>(k, grid, s);
+            case 5: return launch_partial<E, 1, 4, 5, 32>(k, grid, s);
+        }
+    } else if (c.RB == 2 && c.KS == 2 && c.QT == 5) {
+        return launch_partial<E, 2, 2, 5, 32>(k, grid, s);
+    } else if (c.RB == 4 && c.KS == 1 && c.QT == 5) {
+        return launch_partial<E, 4, 1, 5, 64>(k, grid, s);
+    } else if (c.RB == 4 && c.KS == 1 && c.QT == 6) {
+        return launch_partial<E, 4, 1, 6, 64>(k, grid, s);
+    }
+    LS_FAIL(LS_ERR_UNSUPPORTED, "no kernel for RB=%d KS=%d QT=%d", c.RB, c.KS, c.QT);
+}
+
+int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s, WsLayout* out_layout) {
+    int rc = validate(d);
+    if (rc) return rc;
+    const int g = d->H / d->Hkv;
+    const Cfg c = pick_cfg(g * d->sq);
+    const int n_splits = pick_splits(d, c);
+    const WsLayout w = ws_layout(d, c, n_splits);
+    if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
+    AttnK k;
+    k.q = d->q;
+    k.k_cache = d->k_cache;
+    k.v_cache = d->v_cache;
+    k.k_cache_w = d->k_cache;
+    k.v_cache_w = d->v_cache;
+    k.k_new = d->k_new;
+    k.v_new = d->v_new;
+    k.cache_seqlens = d->cache_seqlens;
+    k.mask_bits = d->mask_bits;
+    char* base = static_cast<char*>(ws);
+    k.parts_o = reinterpret_cast<float*>(base + w.parts_o);
+    k.parts_lse = reinterpret_cast<float*>(base + w.parts_lse);
+    k.new_o = reinterpret_cast<float*>(base + w.new_o);
+    k.new_lse = reinterpret_cast<float*>(base + w.new_lse);
+    k.b = d->b; k.sq = d->sq; k.H = d->H; k.Hkv = d->Hkv; k.g = g; k.M = g * d->sq;
+    k.has_new = d->new_mode != LS_NEW_NONE;
+    k.new_mode = d->new_mode;
+    k.n_new = d->n_new;
+    k.n_new_cached = d->n_new_cached;
+    k.mask_words = d->mask_words;
+    k.scatter_new = d->scatter_new;
+    k.prescale_q = d->prescale_q;
+    k.causal = d->causal;
+    k.window_left = d->window_left;
+    k.n_app = d->n_app;
+    k.n_splits = n_splits;
+    k.row_chunks = c.row_chunks;
+    k.rows_per_chunk = c.rows_per_chunk;
+    k.scale = d->softmax_scale;
+    k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
+    k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
+    k.kn_sb = d->kn_stride_b; k.kn_ss = d->kn_stride_s; k.kn_sh = d->kn_stride_h;
+    dim3 grid(n_splits + k.has_new, d->Hkv * c.row_chunks, d->b);
+    rc = d->dtype == LS_F16 ? dispatch_partial<ElemF16>(c, k, grid, s) : dispatch_partial<ElemBF16>(c, k, grid, s);
+    if (out_layout) *out_layout = w;
+    return rc;
+}
+
+int run_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, const float* new_o,
+               const float* new_lse, int mode, void* out, float* o32, float* lse, hipStream_t s) {
+    FinK f;
+    f.parts_o = parts_o;
+    f.parts_lse = parts_lse;
+    f.new_o = new_o;
+    f.new_lse = new_lse;
+    f.out = out;
+    f.o32 = o32;
+    f.lse_out = lse;
+    f.n_parts = n_parts;
+    f.b = d->b; f.sq = d->sq; f.H = d->H;
+    f.mode = mode;
+    f.out_sb = d->out_stride_b; f.out_ss = d->out_stride_s; f.out_sh = d->out_stride_h;
+    dim3 grid((d->sq + 7) / 8, d->H, d->b);
+    if (d->dtype == LS_F16)
+        hipLaunchKernelGGL(attn_finish_kernel<ElemF16>, grid, dim3(256), 0, s, f);
+    else
+        hipLaunchKernelGGL(attn_finish_kernel<ElemBF16>, grid, dim3(256), 0, s, f);
+    LS_CHECK_LAUNCH("attn_finish_kernel");
+    return LS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ls_attn_workspace_bytes(const ls_attn_desc* d) {
+    if (validate(d)) return 0;
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    return ws_layout(d, c, pick_splits(d, c)).total;
+}
+
+int ls_attn_num_parts(const ls_attn_desc* d) {
+    if (validate(d)) return LS_ERR_INVALID_ARG;
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    return pick_splits(d, c) * c.KS;
+}
+
+int ls_attn_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) {
+    return run_partial(d, ws, ws_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int ls_attn_fwd(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) {
+    WsLayout w;
+    int rc = run_partial(d, ws, ws_bytes, static_cast<hipStream_t>(stream), &w);
+    if (rc) return rc;
+    if (!d->out) LS_FAIL(LS_ERR_INVALID_ARG, "out is null");
+    if (d->lse && d->new_mode != LS_NEW_NONE && d->new_mode != LS_NEW_FLASH)
+        LS_FAIL(LS_ERR_INVALID_ARG, "lse output only for LS_NEW_NONE/LS_NEW_FLASH");
+    char* base = static_cast<char*>(ws);
+    const bool has_new = d->new_mode != LS_NEW_NONE;
+    return run_finish(d, reinterpret_cast<float*>(base + w.parts_o), reinterpret_cast<float*>(base + w.parts_lse),
+                      w.n_parts, has_new ? reinterpret_cast<float*>(base + w.new_o) : nullptr,
+                      has_new ? reinterpret_cast<float*>(base + w.new_lse) : nullptr, d->new_mode, d->out, nullptr,
+                      d->lse, static_cast<hipStream_t>(stream));
+}
+
+int ls_attn_reduce_local(const ls_attn_desc* d, void* ws, size_t ws_bytes, float* o32, float* lse, void* stream) {
+    if (validate(d)) return LS_ERR_INVALID_ARG;
+    if (!o32 || !lse) LS_FAIL(LS_ERR_INVALID_ARG, "o32/lse null");
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const WsLayout w = ws_layout(d, c, pick_splits(d, c));
+    if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
+    char* base = static_cast<char*>(ws);
+    return run_finish(d, reinterpret_cast<float*>(base + w.parts_o), reinterpret_cast<float*>(base + w.parts_lse),
+                      w.n_parts, nullptr, nullptr, LS_NEW_NONE, nullptr, o32, lse, static_cast<hipStream_t>(stream));
+}
+
+int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, void* ws,
+                   size_t ws_bytes, void* stream) {
+    if (validate(d)) return LS_ERR_INVALID_ARG;
+    if (!parts_o || !parts_lse || n_parts < 1 || !d->out) LS_FAIL(LS_ERR_INVALID_ARG, "parts/out null");
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const WsLayout w = ws_layout(d, c, pick_splits(d, c));
+    const bool has_new = d->new_mode != LS_NEW_NONE;
+    if (has_new && (!ws || ws_bytes < w.total)) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
+    char* base = static_cast<char*>(ws);
+    return run_finish(d, parts_o, parts_lse, n_parts, has_new ? reinterpret_cast<float*>(base + w.new_o) : nullptr,
+                      has_new ? reinterpret_cast<float*>(base + w.new_lse) : nullptr, d->new_mode, d->out, nullptr,
+                      d->lse, static_cast<hipStream_t>(stream));
+}
+
+int ls_lse_merge(const float* parts_o, const float* parts_lse, int n_parts, int b, int sq, int H, int dtype, void* out,
+                 float* o32, float* lse, void* stream) {
+    if (!parts_o || !parts_lse || n_parts < 1 || b < 1 || sq < 1 || H < 1) LS_FAIL(LS_ERR_INVALID_ARG, "bad merge args");
+    ls_attn_desc d = {};
+    d.b = b; d.sq = sq; d.H = H; d.dtype = dtype;
+    d.out_stride_h = D; d.out_stride_s = (int64_t)H * D; d.out_stride_b = (int64_t)sq * H * D;
+    return run_finish(&d, parts_o, parts_lse, n_parts, nullptr, nullptr, LS_NEW_NONE, out, o32, lse,
+                      static_cast<hipStream_t>(stream));
+}
+
+int ls_pack_tree_mask(const int64_t* tree_mask, int b, int M, int N, uint32_t* bits, int words, void* stream) {
+    if (!tree_mask || !bits || b < 1 || M < 1 || N < 1 || words * 32 < N) LS_FAIL(LS_ERR_INVALID_ARG, "bad mask args");
+    const int rows = b * M;
+    hipLaunchKernelGGL(pack_mask_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       tree_mask, M, N, bits, words, rows);
+    LS_CHECK_LAUNCH("pack_mask_kernel");
+    return LS_OK;
+}
+
+}  // extern "C"

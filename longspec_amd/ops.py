@@ -1,0 +1,400 @@
+"""Operator layer: torch tensors in, HIP kernels (through the C ABI) out.
+
+One function per reference seam of the draft-then-verify round:
+
+  kvcache_attention      flash_attn_with_kvcache   longspec/test/llama.py:324,385, llama_glide.py:261,265,297,300
+  verify_attention       LlamaAttention.tree_decoding + tree_part_fwd + merge   llama.py:385-387,394-421
+  draft_tree_attention   GlideAttention.tree_decoding (self-attn) + triton_tree_part_fwd  llama_glide.py:300-329
+  tree_attention         triton_tree_attn.attention   triton_tree_attn.py:19-77
+  rmsnorm / rope_*       LlamaRMSNorm / LlamaRotaryEmbedding / apply_rotary_pos_emb (transformers)
+  tree_collapse          LlamaGlide.tree_verification  llama_glide.py:1128-1175
+  lse_merge              N-way form of llama.py:385-387,420 for sequence-sharded prefix KV
+
+Everything runs on the CURRENT torch stream, without host synchronisation.  There is
+no fallback: a missing extension or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _C
+from ._C import LS_NEW_DRAFT, LS_NEW_FLASH, LS_NEW_NONE, LS_NEW_TARGET, AttnDesc
+
+_DT = {torch.float16: _C.LS_F16, torch.bfloat16: _C.LS_BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dtype(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (fp16/bf16 only)") from None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("longspec_amd ops run on the GPU only (no CPU path): got a CPU tensor")
+
+
+class _Workspace:
+    """Per-device scratch for split-KV partials, grown on demand.  Calls on one stream are
+    ordered, so one buffer per (device, stream) is reused by every call."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device, nbytes: int) -> torch.Tensor:
+        key = (device.index, _stream())
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+_causal_bits = {}
+
+
+def causal_mask_bits(n: int, device) -> torch.Tensor:
+    """Packed lower-triangular mask [1, n, words]: row r sees new keys j <= r."""
+    key = (n, device.index)
+    t = _causal_bits.get(key)
+    if t is None:
+        words = (n + 31) // 32
+        rows = []
+        for r in range(n):
+            v = (1 << (r + 1)) - 1
+            rows.append([(v >> (32 * w)) & 0xFFFFFFFF for w in range(words)])
+        t = torch.tensor(rows, dtype=torch.int64).to(torch.int32).view(1, n, words).to(device)   # wraps to the same bits
+        _causal_bits[key] = t
+    return t
+
+
+def pack_tree_mask(tree_mask: torch.Tensor) -> torch.Tensor:
+    """int64 [b,M,N] 0/1 mask -> packed uint32 [b,M,ceil(N/32)] (stored as int32)."""
+    _dev(tree_mask)
+    if tree_mask.dtype != torch.int64:
+        tree_mask = tree_mask.to(torch.int64)
+    tree_mask = tree_mask.contiguous()
+    b, M, N = tree_mask.shape
+    words = (N + 31) // 32
+    bits = torch.empty((b, M, words), dtype=torch.int32, device=tree_mask.device)
+    lib = _C.load()
+    _C.check(lib.ls_pack_tree_mask(tree_mask.data_ptr(), b, M, N, bits.data_ptr(), words, _stream()), "ls_pack_tree_mask")
+    return bits
+
+
+def _check_qkv(q, k_cache, v_cache):
+    if q.dim() != 4 or q.shape[-1] != 128:
+        raise ValueError(f"q must be [b,sq,H,128], got {tuple(q.shape)}")
+    if k_cache.dim() != 4 or k_cache.shape[-1] != 128 or k_cache.shape != v_cache.shape:
+        raise ValueError("k_cache/v_cache must be [b,S,Hkv,128] and equal-shaped")
+    if q.stride(-1) != 1 or k_cache.stride(-1) != 1 or v_cache.stride(-1) != 1:
+        raise ValueError("innermost dimension must be contiguous")
+    if k_cache.stride() != v_cache.stride():
+        raise ValueError("k_cache and v_cache must share strides")
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise TypeError("q/k_cache/v_cache dtypes differ")
+
+
+def _desc(q, k_cache, v_cache, cache_seqlens, kv_len_hint, k_new=None, v_new=None, mask_bits=None, out=None,
+          lse=None, new_mode=LS_NEW_NONE, n_new=0, n_new_cached=0, scatter_new=0, causal=False, window_left=-1,
+          n_app=0, prescale_q=False, softmax_scale=None, n_splits=0) -> AttnDesc:
+    b, sq, H, D = q.shape
+    Hkv = k_cache.shape[2]
+    d = AttnDesc()
+    d.q = q.data_ptr()
+    d.k_cache = k_cache.data_ptr()
+    d.v_cache = v_cache.data_ptr()
+    d.k_new = k_new.data_ptr() if k_new is not None else None
+    d.v_new = v_new.data_ptr() if v_new is not None else None
+    if cache_seqlens.dtype != torch.int32:
+        cache_seqlens = cache_seqlens.to(torch.int32)
+    d._keep = (cache_seqlens,)          # keep the converted tensor alive for the launch
+    d.cache_seqlens = cache_seqlens.data_ptr()
+    d.mask_bits = mask_bits.data_ptr() if mask_bits is not None else None
+    d.out = out.data_ptr() if out is not None else None
+    d.lse = lse.data_ptr() if lse is not None else None
+    d.b, d.sq, d.H, d.Hkv = b, sq, H, Hkv
+    d.dtype = _dtype(q)
+    d.new_mode = new_mode
+    d.n_new = n_new
+    d.n_new_cached = n_new_cached
+    d.mask_words = mask_bits.shape[-1] if mask_bits is not None else 0
+    d.scatter_new = int(scatter_new)
+    d.causal = int(causal)
+    d.window_left = int(window_left)
+    d.n_app = int(n_app)
+    d.prescale_q = int(prescale_q)
+    d.kv_len_hint = int(kv_len_hint)
+    d.n_splits = int(n_splits)
+    d.softmax_scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    d.q_stride_b, d.q_stride_s, d.q_stride_h = q.stride(0), q.stride(1), q.stride(2)
+    d.kc_stride_b, d.kc_stride_s, d.kc_stride_h = k_cache.stride(0), k_cache.stride(1), k_cache.stride(2)
+    if k_new is not None:
+        if k_new.stride() != v_new.stride() or k_new.stride(-1) != 1:
+            raise ValueError("k_new/v_new must share strides and be contiguous in the last dim")
+        d.kn_stride_b, d.kn_stride_s, d.kn_stride_h = k_new.stride(0), k_new.stride(1), k_new.stride(2)
+    if out is not None:
+        d.out_stride_b, d.out_stride_s, d.out_stride_h = out.stride(0), out.stride(1), out.stride(2)
+    return d
+
+
+def _hint(cache_seqlens, kv_len_hint, k_cache):
+    if kv_len_hint is None:
+        # no host-side bound known: size the grid for the whole cache allocation (no sync)
+        return int(k_cache.shape[1])
+    return int(kv_len_hint)
+
+
+def _run(d: AttnDesc, device):
+    lib = _C.load()
+    nbytes = lib.ls_attn_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        _C.check(-1, "ls_attn_workspace_bytes")
+    ws = _ws.get(device, nbytes)
+    _C.check(lib.ls_attn_fwd(C.byref(d), ws.data_ptr(), ws.numel(), _stream()), "ls_attn_fwd")
+
+
+def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, causal=False, window_size=(-1, -1),
+                      return_softmax_lse=False, softmax_scale=None, kv_len_hint: Optional[int] = None, n_splits=0):
+    """``flash_attn_with_kvcache`` as the reference uses it.  New
+    ``k``/``v`` rows are appended IN PLACE at ``cache_seqlens`` and attended causally
+    (the reference only appends with ``causal=True``)."""
+    _dev(q, k_cache, v_cache, k, v, cache_seqlens)
+    _check_qkv(q, k_cache, v_cache)
+    b, sq, H, D = q.shape
+    if window_size[1] not in (-1, 0):
+        raise NotImplementedError("right window other than -1/0")
+    out = torch.empty((b, sq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((b, H, sq), dtype=torch.float32, device=q.device) if return_softmax_lse else None
+    hint = _hint(cache_seqlens, kv_len_hint, k_cache)
+    if k is not None:
+        if not causal:
+            raise NotImplementedError("append without causal=True is not a reference call pattern")
+        n = k.shape[1]
+        if n != sq:
+            raise ValueError("appended rows must equal query rows")
+        bits = causal_mask_bits(n, q.device).expand(b, -1, -1).contiguous()
+        d = _desc(q, k_cache, v_cache, cache_seqlens, hint, k_new=k, v_new=v, mask_bits=bits, out=out, lse=lse,
+                  new_mode=LS_NEW_FLASH, n_new=n, scatter_new=1, causal=True, window_left=window_size[0], n_app=n,
+                  softmax_scale=softmax_scale, n_splits=n_splits)
+    else:
+        d = _desc(q, k_cache, v_cache, cache_seqlens, hint, out=out, lse=lse, causal=causal or window_size[1] == 0,
+                  window_left=window_size[0], softmax_scale=softmax_scale, n_splits=n_splits)
+    _run(d, q.device)
+    return (out, lse) if return_softmax_lse else out
+
+
+def verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, last_layer: bool,
+                     softmax_scale: float = 1.0 / (128 ** 0.5), kv_len_hint: Optional[int] = None, n_splits=0):
+    """Hybrid tree-verification attention of one target layer (K1+K2+K3 fused):
+    prefix flash-decoding over ``cache[:, :cache_lens]`` + scatter of the R new K/V rows at
+    ``cache_lens`` + tree-masked part + fp16 merge.  ``mask_bits`` = ``pack_tree_mask`` of
+    the [b,R,R] verification mask.  Returns [b,R,H,128]."""
+    _dev(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits)
+    _check_qkv(q, k_cache, v_cache)
+    b, R, H, D = q.shape
+    out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
+    d = _desc(q, k_cache, v_cache, cache_lens, _hint(cache_lens, kv_len_hint, k_cache), k_new=k_new, v_new=v_new,
+              mask_bits=mask_bits, out=out, new_mode=LS_NEW_TARGET, n_new=R, scatter_new=1, prescale_q=last_layer,
+              softmax_scale=softmax_scale, n_splits=n_splits)
+    _run(d, q.device)
+    return out
+
+
+def draft_tree_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, N: int, window: int = 512,
+                         kv_len_hint: Optional[int] = None):
+    """Draft self-attention of a tree step (K5+K6 fused): window prefix over rows [0,p) +
+    scatter of the M new rows at ``p + [N-M, N)`` + tree-masked part over rows ``p + [0,N)``
+    + fp32 merge.  ``cache_lens`` = p.  Returns [b,M,H,128]."""
+    _dev(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits)
+    _check_qkv(q, k_cache, v_cache)
+    b, M, H, D = q.shape
+    out = torch.empty((b, M, H, D), dtype=q.dtype, device=q.device)
+    d = _desc(q, k_cache, v_cache, cache_lens, _hint(cache_lens, kv_len_hint, k_cache), k_new=k_new, v_new=v_new,
+              mask_bits=mask_bits, out=out, new_mode=LS_NEW_DRAFT, n_new=N, n_new_cached=N - M, scatter_new=1,
+              window_left=window)
+    _run(d, q.device)
+    return out
+
+
+def lse_merge(parts_o: torch.Tensor, parts_lse: torch.Tensor, dtype=None, want_o32=False):
+    """parts_o [W,b,sq,H,128] fp32, parts_lse [W,b,H,sq] fp32 -> merged out (dtype) and/or (o32, lse)."""
+    _dev(parts_o, parts_lse)
+    W, b, sq, H, D = parts_o.shape
+    parts_o = parts_o.contiguous()
+    parts_lse = parts_lse.contiguous()
+    out = torch.empty((b, sq, H, D), dtype=dtype, device=parts_o.device) if dtype is not None else None
+    o32 = torch.empty((b, sq, H, D), dtype=torch.float32, device=parts_o.device) if want_o32 else None
+    lse = torch.empty((b, H, sq), dtype=torch.float32, device=parts_o.device)
+    lib = _C.load()
+    _C.check(lib.ls_lse_merge(parts_o.data_ptr(), parts_lse.data_ptr(), W, b, sq, H,
+                              _DT[dtype] if dtype is not None else 0,
+                              out.data_ptr() if out is not None else None,
+                              o32.data_ptr() if o32 is not None else None, lse.data_ptr(), _stream()), "ls_lse_merge")
+    return out, o32, lse
+
+
+# ---- multi-GPU building blocks (sequence-sharded prefix KV) -------------------------------------
+class ShardedAttnCall:
+    """Stage 1 / exchange / stage 2 of one attention call whose prefix KV is sharded by
+    sequence over ranks.  Usage: ``partial()`` -> (o32, lse) of the LOCAL
+    prefix rows; all-gather those over ranks; ``finish(parts_o, parts_lse)``."""
+
+    def __init__(self, desc: AttnDesc, out: torch.Tensor, device):
+        self.d = desc
+        self.out = out
+        self.device = device
+        lib = _C.load()
+        nbytes = lib.ls_attn_workspace_bytes(C.byref(desc))
+        if nbytes == 0:
+            _C.check(-1, "ls_attn_workspace_bytes")
+        # the new-block part must survive until finish(): private workspace
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def partial(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        lib = _C.load()
+        d = self.d
+        _C.check(lib.ls_attn_partial(C.byref(d), self.ws.data_ptr(), self.ws.numel(), _stream()), "ls_attn_partial")
+        o32 = torch.empty((d.b, d.sq, d.H, 128), dtype=torch.float32, device=self.device)
+        lse = torch.empty((d.b, d.H, d.sq), dtype=torch.float32, device=self.device)
+        _C.check(lib.ls_attn_reduce_local(C.byref(d), self.ws.data_ptr(), self.ws.numel(), o32.data_ptr(),
+                                          lse.data_ptr(), _stream()), "ls_attn_reduce_local")
+        return o32, lse
+
+    def finish(self, parts_o: torch.Tensor, parts_lse: torch.Tensor) -> torch.Tensor:
+        lib = _C.load()
+        parts_o = parts_o.contiguous()
+        parts_lse = parts_lse.contiguous()
+        _C.check(lib.ls_attn_finish(C.byref(self.d), parts_o.data_ptr(), parts_lse.data_ptr(), parts_o.shape[0],
+                                    self.ws.data_ptr(), self.ws.numel(), _stream()), "ls_attn_finish")
+        return self.out
+
+
+def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits, last_layer,
+                             softmax_scale=1.0 / (128 ** 0.5), kv_len_hint=None) -> ShardedAttnCall:
+    """Like ``verify_attention`` but ``k_cache/v_cache`` hold only this rank's prefix rows
+    (``local_lens`` valid rows); the new rows are scattered at ``local_lens`` of the LOCAL
+    cache (only the tail-owning rank's copy is ever read back as prefix)."""
+    _dev(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits)
+    _check_qkv(q, k_cache, v_cache)
+    b, R, H, D = q.shape
+    out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
+    d = _desc(q, k_cache, v_cache, local_lens, _hint(local_lens, kv_len_hint, k_cache), k_new=k_new, v_new=v_new,
+              mask_bits=mask_bits, out=out, new_mode=LS_NEW_TARGET, n_new=R, scatter_new=1, prescale_q=last_layer,
+              softmax_scale=softmax_scale)
+    return ShardedAttnCall(d, out, q.device)
+
+
+def sharded_prefix_attention(q, k_cache, v_cache, local_lens, kv_len_hint=None) -> ShardedAttnCall:
+    """Non-causal prefix attention over a local KV shard (draft cross-attention, K7)."""
+    _dev(q, k_cache, v_cache, local_lens)
+    _check_qkv(q, k_cache, v_cache)
+    b, R, H, D = q.shape
+    out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
+    d = _desc(q, k_cache, v_cache, local_lens, _hint(local_lens, kv_len_hint, k_cache), out=out)
+    return ShardedAttnCall(d, out, q.device)
+
+
+# ---- RMSNorm / RoPE ----------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None):
+    """y = LlamaRMSNorm(x [+ residual]).  With ``residual`` returns (y, x + residual)."""
+    _dev(x, weight, residual)
+    hidden = x.shape[-1]
+    xc = x.contiguous()
+    rows = xc.numel() // hidden
+    y = torch.empty_like(xc)
+    lib = _C.load()
+    if residual is not None:
+        rc = residual.contiguous()
+        s = torch.empty_like(xc)
+        _C.check(lib.ls_rmsnorm_fwd(xc.data_ptr(), rc.data_ptr(), weight.data_ptr(), y.data_ptr(), s.data_ptr(), rows,
+                                    hidden, eps, _dtype(x), _stream()), "ls_rmsnorm_fwd")
+        return y.view(x.shape), s.view(x.shape)
+    _C.check(lib.ls_rmsnorm_fwd(xc.data_ptr(), None, weight.data_ptr(), y.data_ptr(), None, rows, hidden, eps,
+                                _dtype(x), _stream()), "ls_rmsnorm_fwd")
+    return y.view(x.shape)
+
+
+def rope_cos_sin(position_ids: torch.Tensor, inv_freq: torch.Tensor, attention_scaling: float, dtype):
+    """position_ids [b,R] int64, inv_freq [64] fp32 -> cos, sin [b,R,128] dtype."""
+    _dev(position_ids, inv_freq)
+    pos = position_ids.to(torch.int64).contiguous()
+    b, R = pos.shape
+    cos = torch.empty((b, R, 128), dtype=dtype, device=pos.device)
+    sin = torch.empty((b, R, 128), dtype=dtype, device=pos.device)
+    lib = _C.load()
+    _C.check(lib.ls_rope_cos_sin(pos.data_ptr(), inv_freq.data_ptr(), float(attention_scaling), cos.data_ptr(),
+                                 sin.data_ptr(), b * R, _DT[dtype], _stream()), "ls_rope_cos_sin")
+    return cos, sin
+
+
+def rope_apply_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor):
+    """In-place apply_rotary_pos_emb(unsqueeze_dim=2) on q [b,R,Hq,128], k [b,R,Hk,128]
+    (views into a fused QKV buffer are fine: only the row stride must be uniform)."""
+    _dev(q, k, cos, sin)
+    b, R, Hq, D = q.shape
+    Hk = k.shape[2]
+    for t in (q, k):
+        if t.stride(-1) != 1 or t.stride(2) != 128 or (b > 1 and t.stride(0) != R * t.stride(1)):
+            raise ValueError("rope_apply_: heads must be packed (stride 128) and rows uniformly strided")
+    lib = _C.load()
+    _C.check(lib.ls_rope_apply(q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), b * R, Hq, Hk, q.stride(1),
+                               k.stride(1), _dtype(q), _stream()), "ls_rope_apply")
+    return q, k
+
+
+def tree_positions(tree_mask: torch.Tensor, base: Optional[torch.Tensor]) -> torch.Tensor:
+    """position_ids = tree_mask.sum(-1) - 1 + base[:, None]  (llama.py:575-577)."""
+    _dev(tree_mask, base)
+    tm = tree_mask.to(torch.int64).contiguous()
+    b, M, N = tm.shape
+    pos = torch.empty((b, M), dtype=torch.int64, device=tm.device)
+    if base is not None and base.dtype != torch.int32:
+        base = base.to(torch.int32)
+    lib = _C.load()
+    _C.check(lib.ls_tree_positions(tm.data_ptr(), base.data_ptr() if base is not None else None, b, M, N,
+                                   pos.data_ptr(), _stream()), "ls_tree_positions")
+    return pos
+
+
+def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: int, max_acc: int,
+                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None):
+    """Accept/reject tree collapse + last-layer KV row move, one launch, no host sync.
+    Returns (acc_ids [b,max_acc] int64 zero-padded, acc_num [b] int64, double_input [b] int32,
+    index_mapping [b,max_acc] int64, -1 padded)."""
+    _dev(all_spec, all_llm_pred, tree_mask, cache_lens, k_cache, v_cache)
+    b, Fn = all_spec.shape
+    dev = all_spec.device
+    spec = all_spec.to(torch.int64).contiguous()
+    pred = all_llm_pred.to(torch.int64).contiguous()
+    tm = tree_mask.to(torch.int64).contiguous()
+    cl = cache_lens.to(torch.int32).contiguous()
+    acc_ids = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
+    acc_num = torch.empty((b,), dtype=torch.int64, device=dev)
+    dbl = torch.empty((b,), dtype=torch.int32, device=dev)
+    imap = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
+    lib = _C.load()
+    if k_cache is not None:
+        if k_cache.stride() != v_cache.stride() or k_cache.stride(3) != 1 or k_cache.stride(2) != k_cache.shape[3]:
+            raise ValueError("tree_collapse: cache rows must be contiguous [Hkv*D]")
+        row_elems = k_cache.shape[2] * k_cache.shape[3]
+        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), b, Fn, non_leaf_len,
+                                      max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(), imap.data_ptr(),
+                                      k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+                                      row_elems, _dtype(k_cache), _stream()), "ls_tree_collapse")
+    else:
+        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), b, Fn, non_leaf_len,
+                                      max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(), imap.data_ptr(),
+                                      None, None, 0, 0, 0, 0, _stream()), "ls_tree_collapse")
+    return acc_ids, acc_num, dbl, imap

@@ -1,0 +1,355 @@
+"""Parity of the HIP kernels (called through the C ABI) against the reference's golden
+vectors and the CPU oracle.  ``-m gpu``: needs a real MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import toy
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from longspec_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def g(t):
+    return t.to(DEV) if torch.is_tensor(t) else t
+
+
+def assert_close_f16(got, want, atol=1.1e-3, frac=0.02, what=""):
+    """Reference-order restatement parity: at most one fp16 ulp (|o| <~ 2) on a small fraction."""
+    d = (got.float().cpu() - want.float().cpu()).abs()
+    assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
+    assert d.max().item() <= atol, f"{what}: max |diff| {d.max().item():.3e} > {atol}"
+    assert (d > 0).float().mean().item() <= frac, f"{what}: {(d > 0).float().mean().item():.3%} elements differ"
+
+
+# --------------------------------------------------------------------------- #
+# RMSNorm / RoPE / positions
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("c", list(cases.norm_cases()), ids=lambda c: c["name"])
+def test_rmsnorm_golden(ops, c):
+    y = ops.rmsnorm(g(c["x"]), g(c["w"]), c["eps"])
+    # fp32 reduction order differs from torch's: allow one fp16 ulp on a sliver of elements
+    assert_close_f16(y, c["y"], atol=4e-3, frac=0.002, what="rmsnorm")
+
+
+def test_rmsnorm_residual(ops):
+    x = toy.randn_f16((3, 74, 4096), 1)
+    r = toy.randn_f16((3, 74, 4096), 2)
+    w = toy.randn_f16((4096,), 3) * 0.1 + 1
+    y, s = ops.rmsnorm(g(x), g(w), 1e-5, residual=g(r))
+    s_ref = r + x
+    assert torch.equal(s.cpu(), s_ref)
+    assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=8e-3, frac=0.002, what="rmsnorm+res")
+
+
+@pytest.mark.parametrize("c", list(cases.rope_cases()), ids=lambda c: c["name"])
+def test_rope_golden(ops, c):
+    cos, sin = ops.rope_cos_sin(g(c["pos"]), g(c["inv_freq"]), c["scaling"], torch.float16)
+    # cos/sin of arguments up to 2.6e5 rad: double-precision evaluation -> same fp16 table as glibc
+    for got, want in ((cos, c["cos"]), (sin, c["sin"])):
+        d = (got.float().cpu() - want.float()).abs()
+        assert d.max().item() <= 1e-3 and (d > 0).float().mean().item() < 1e-3
+    q, k = g(c["q"]).clone(), g(c["k"]).clone()
+    ops.rope_apply_(q, k, g(c["cos"]), g(c["sin"]))
+    assert torch.equal(q.cpu(), c["q_out"]) and torch.equal(k.cpu(), c["k_out"])
+
+
+def test_rope_apply_strided_views(ops):
+    """q/k as views of one fused QKV buffer (row stride != heads*128)."""
+    Hq, Hk, R = 4, 2, 9
+    qkv = toy.randn_f16((1, R, (Hq + 2 * Hk) * 128), 5)
+    cos, sin = ref_ops.rope_cos_sin(torch.arange(100, 100 + R)[None], 1.0 / (10000 ** (torch.arange(0, 128, 2).float() / 128)))
+    buf = g(qkv).clone()
+    q = buf[..., :Hq * 128].view(1, R, Hq, 128)
+    k = buf[..., Hq * 128:(Hq + Hk) * 128].view(1, R, Hk, 128)
+    ops.rope_apply_(q, k, g(cos), g(sin))
+    qr = ref_ops.apply_rope(qkv[..., :Hq * 128].view(1, R, Hq, 128), cos, sin)
+    kr = ref_ops.apply_rope(qkv[..., Hq * 128:(Hq + Hk) * 128].view(1, R, Hk, 128), cos, sin)
+    assert torch.equal(q.cpu(), qr) and torch.equal(k.cpu(), kr)
+    assert torch.equal(buf[..., (Hq + Hk) * 128:].cpu(), qkv[..., (Hq + Hk) * 128:])
+
+
+def test_pack_mask_and_positions(ops):
+    for seed, a in ((1, 1), (2, 3), (3, 6)):
+        parents = toy.random_beam_tree(cases.TREE, seed)
+        vm = torch.from_numpy(toy.verify_mask(toy.tree_mask_from_parents(parents), a=a, gamma=5))[None]
+        bits = ops.pack_tree_mask(g(vm)).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        R = vm.shape[1]
+        for r in range(R):
+            for j in range(96):
+                want = int(vm[0, r, j]) if j < R else 0
+                assert ((bits[0, r, j // 32] >> (j % 32)) & 1) == want
+        base = torch.tensor([1234], dtype=torch.int32)
+        pos = ops.tree_positions(g(vm), g(base)).cpu()
+        assert torch.equal(pos, vm.sum(-1) - 1 + 1234)
+
+
+# --------------------------------------------------------------------------- #
+# tree collapse
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("c", list(cases.tree_verification_cases()), ids=lambda c: c["name"])
+def test_tree_collapse_golden(ops, c):
+    Fn = c["spec"].shape[1]
+    depth = int(c["mask"].sum(-1).max())
+    kc, vc = g(c["kc"]).clone(), g(c["vc"]).clone()
+    acc_ids, acc_num, dbl, imap = ops.tree_collapse(g(c["spec"]), g(c["pred"]), g(c["mask"]),
+                                                    g(torch.tensor([c["cache_len"]], dtype=torch.int32)),
+                                                    c["non_leaf_len"], depth, kc, vc)
+    n = int(c["acc_num"][0])
+    assert int(acc_num[0]) == n
+    assert torch.equal(acc_ids[:, :n].cpu(), c["acc_ids"][:, :n])
+    assert int(dbl[0]) == int(c["double_input"][0])
+    assert (imap[0, n:] == -1).all()
+    assert torch.equal(kc.cpu(), c["kc_after"]) and torch.equal(vc.cpu(), c["vc_after"])
+
+
+def test_tree_collapse_batched_and_large(ops):
+    """b = 3 independent rows; F = 341 (tree 4/16/64/256) against the oracle."""
+    shape = [4, 16, 64, 256]
+    specs, preds, masks = [], [], []
+    rng = np.random.RandomState(5)
+    for z in range(3):
+        parents = toy.random_beam_tree(shape, 40 + z)
+        m = toy.tree_mask_from_parents(parents)
+        spec = rng.randint(2, 9, size=m.shape[0])
+        pred = rng.randint(2, 9, size=m.shape[0])
+        specs.append(spec), preds.append(pred), masks.append(m)
+    spec = torch.from_numpy(np.stack(specs))
+    pred = torch.from_numpy(np.stack(preds))
+    mask = torch.from_numpy(np.stack(masks))
+    acc_ids, acc_num, dbl, imap = ops.tree_collapse(g(spec), g(pred), g(mask), g(torch.zeros(3, dtype=torch.int32)), 85, 5)
+    for z in range(3):
+        r_ids, r_num, r_dbl, r_map = ref_ops.tree_verification(spec[z:z + 1], pred[z:z + 1], mask[z:z + 1], 85)
+        n = int(r_num[0])
+        assert int(acc_num[z]) == n and int(dbl[z]) == int(r_dbl[0])
+        assert torch.equal(acc_ids[z, :n].cpu(), r_ids[0, :n]) and torch.equal(imap[z, :n].cpu(), r_map[0, :n])
+
+
+# --------------------------------------------------------------------------- #
+# attention: flash-attn contract (prefix / causal / window / append)
+# --------------------------------------------------------------------------- #
+def _mk_cache(H, Hkv, L, seed, extra=96, b=1):
+    kc = torch.zeros(b, L + extra, Hkv, 128, dtype=torch.float16)
+    vc = torch.zeros(b, L + extra, Hkv, 128, dtype=torch.float16)
+    kc[:, :L] = toy.randn_f16((b, L, Hkv, 128), seed)
+    vc[:, :L] = toy.randn_f16((b, L, Hkv, 128), seed + 1)
+    return kc, vc
+
+
+PREFIX_SHAPES = [
+    # H, Hkv, sq, L
+    (4, 1, 74, 300), (2, 2, 74, 1024), (8, 2, 74, 1), (8, 2, 74, 37), (8, 2, 74, 64), (8, 2, 74, 4096 + 37),
+    (5, 1, 74, 200), (4, 1, 16, 700), (4, 1, 4, 129), (4, 4, 1, 513), (8, 2, 6, 1000), (4, 2, 37, 640),
+    (16, 2, 74, 333),          # g = 8 -> 592 rows = 2 row chunks
+]
+
+
+@pytest.mark.parametrize("H,Hkv,sq,L", PREFIX_SHAPES)
+def test_prefix_attention_vs_oracle(ops, H, Hkv, sq, L):
+    q = toy.randn_f16((1, sq, H, 128), 11)
+    kc, vc = _mk_cache(H, Hkv, L, 12)
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref, lse_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True)
+    o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), return_softmax_lse=True, kv_len_hint=L)
+    assert_close_f16(o, o_ref, what="prefix o")
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("n_splits", [1, 2, 3, 7, 64])
+def test_prefix_split_invariance(ops, n_splits):
+    H, Hkv, sq, L = 8, 2, 74, 2000
+    q = toy.randn_f16((1, sq, H, 128), 21)
+    kc, vc = _mk_cache(H, Hkv, L, 22)
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref, lse_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True)
+    o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), return_softmax_lse=True, kv_len_hint=L + 500,
+                                   n_splits=n_splits)
+    assert_close_f16(o, o_ref, what=f"splits={n_splits}")
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("H,Hkv,sq,L", [(4, 1, 3, 700), (8, 2, 6, 300), (2, 2, 1, 64), (4, 1, 16, 40)])
+def test_causal_cross_attention(ops, H, Hkv, sq, L):
+    """Draft cross-attention step 0: causal, no append (llama_glide.py:265)."""
+    q = toy.randn_f16((1, sq, H, 128), 31)
+    kc, vc = _mk_cache(H, Hkv, L, 32)
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, causal=True)
+    o = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), causal=True, kv_len_hint=L)
+    assert_close_f16(o, o_ref, what="causal")
+
+
+@pytest.mark.parametrize("H,Hkv,sq,L", [(4, 1, 16, 700), (4, 1, 4, 520), (2, 2, 16, 100), (8, 2, 16, 5000)])
+def test_window_noncausal_g3(ops, H, Hkv, sq, L):
+    """Draft tree-step prefix: non-causal window (512,-1) + LSE (gotcha G3)."""
+    q = toy.randn_f16((1, sq, H, 128), 41)
+    kc, vc = _mk_cache(H, Hkv, L, 42)
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref, lse_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, window_size=(512, -1), return_softmax_lse=True)
+    o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), window_size=(512, -1),
+                                   return_softmax_lse=True, kv_len_hint=L)
+    assert_close_f16(o, o_ref, what="window")
+    assert (lse.cpu() - lse_ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("H,Hkv,a,L,window", [(4, 1, 3, 700, 512), (8, 2, 6, 100, 512), (2, 2, 1, 600, 512),
+                                              (4, 1, 1, 300, -1), (8, 2, 5, 2000, -1)])
+def test_append_causal(ops, H, Hkv, a, L, window):
+    """Append + causal (+ window): target decode llama.py:324, draft step 0 llama_glide.py:261."""
+    q = toy.randn_f16((1, a, H, 128), 51)
+    k = toy.randn_f16((1, a, Hkv, 128), 52)
+    v = toy.randn_f16((1, a, Hkv, 128), 53)
+    kc, vc = _mk_cache(H, Hkv, L, 54)
+    cl = torch.tensor([L], dtype=torch.int32)
+    kc_r, vc_r = kc.clone(), vc.clone()
+    o_ref = ref_ops.kvcache_attention(q, kc_r, vc_r, k, v, cache_seqlens=cl, causal=True, window_size=(window, -1))
+    kc_g, vc_g = g(kc), g(vc)
+    o = ops.kvcache_attention(g(q), kc_g, vc_g, g(k), g(v), cache_seqlens=g(cl), causal=True, window_size=(window, -1),
+                              kv_len_hint=L)
+    assert_close_f16(o, o_ref, what="append")
+    assert torch.equal(kc_g.cpu(), kc_r) and torch.equal(vc_g.cpu(), vc_r)
+
+
+def test_batched_ragged(ops):
+    """b = 3 with ragged cache_seqlens (0, 77, 1000)."""
+    H, Hkv, sq = 4, 2, 5
+    lens = [0, 77, 1000]
+    q = toy.randn_f16((3, sq, H, 128), 61)
+    kc, vc = _mk_cache(H, Hkv, 1000, 62, b=3)
+    cl = torch.tensor(lens, dtype=torch.int32)
+    o_ref, lse_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True)
+    o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), return_softmax_lse=True, kv_len_hint=1000)
+    assert_close_f16(o[1:], o_ref[1:], what="ragged")
+    assert (o[0] == 0).all() and torch.isinf(lse[0]).all()        # empty prefix: zeros, lse = -inf
+    assert (lse[1:].cpu() - lse_ref[1:]).abs().max().item() <= 2e-5
+
+
+def test_bf16_prefix(ops):
+    H, Hkv, sq, L = 8, 2, 74, 777
+    q = toy.randn_f16((1, sq, H, 128), 71).to(torch.bfloat16)
+    kc, vc = _mk_cache(H, Hkv, L, 72)
+    kc, vc = kc.to(torch.bfloat16), vc.to(torch.bfloat16)
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl)
+    o = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), kv_len_hint=L)
+    assert_close_f16(o, o_ref, atol=8.5e-3, what="bf16")      # one bf16 ulp at |o| ~ 1
+
+
+# --------------------------------------------------------------------------- #
+# hybrid verification attention (golden = the reference's own tree_decoding)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("c", list(cases.verify_cases()), ids=lambda c: c["name"])
+@pytest.mark.parametrize("last_layer", [False, True])
+def test_verify_attention_golden(ops, c, last_layer):
+    kc, vc = g(c["kc"]).clone(), g(c["vc"]).clone()
+    bits = ops.pack_tree_mask(g(c["mask"]))
+    out = ops.verify_attention(g(c["q"]), g(c["k"]), g(c["v"]), kc, vc, g(c["cache_lens"]), bits, last_layer,
+                               kv_len_hint=c["L"])
+    assert_close_f16(out, c["hybrid"][last_layer], atol=2.1e-3, frac=0.05, what="verify")
+    L = c["L"]
+    assert torch.equal(kc[:, L:L + 74].cpu(), c["k"]) and torch.equal(vc[:, L:L + 74].cpu(), c["v"])
+    assert torch.equal(kc[:, :L].cpu(), c["kc"][:, :L])
+    if c["dense"] is not None and not last_layer:
+        assert (out.float().cpu() - c["dense"].float()).abs().max().item() <= 4e-3
+
+
+@pytest.mark.parametrize("c", list(cases.tree_part_cases()), ids=lambda c: c["name"])
+def test_target_tree_part_golden(ops, c):
+    """The tree part alone: empty prefix (cache_lens = 0) makes weight = 0, so the merged
+    output IS current_out -- pinned against LlamaAttention.tree_part_fwd's golden."""
+    kc = torch.zeros_like(c["kc"])
+    vc = torch.zeros_like(c["vc"])
+    bits = ops.pack_tree_mask(g(c["mask"]))
+    out = ops.verify_attention(g(c["q"]), g(c["k"]), g(c["v"]), g(kc), g(vc), g(torch.zeros(1, dtype=torch.int32)), bits,
+                               c["last_layer"], kv_len_hint=0)
+    assert_close_f16(out, c["current_out"], atol=1.1e-3, frac=0.02, what="tree part")
+
+
+@pytest.mark.parametrize("H,Hkv", [(32, 8), (32, 32), (40, 8)])
+def test_verify_attention_model_shapes_vs_oracle(ops, H, Hkv):
+    """Llama-3-8B / Vicuna-7B / QwQ-32B head layouts, ragged L = 4096 + 37, a = 1 and 6."""
+    for a, seed in ((1, 81), (6, 82)):
+        q, k, v, kc, vc, tm = toy.verify_inputs(H, Hkv, 4096 + 37, seed, a=a)
+        cl = torch.tensor([4096 + 37], dtype=torch.int32)
+        kc_r, vc_r = kc.clone(), vc.clone()
+        ref = ref_ops.target_verify_attention(q, k, v, kc_r, vc_r, cl, tm, False)
+        kc_g, vc_g = g(kc), g(vc)
+        out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), False,
+                                   kv_len_hint=4096 + 37)
+        assert_close_f16(out, ref, atol=2.1e-3, frac=0.05, what=f"H={H}")
+        assert torch.equal(kc_g.cpu(), kc_r)
+
+
+# --------------------------------------------------------------------------- #
+# draft self-attention chain (step 0 + 4 tree levels on one cache)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("c", list(cases.draft_cases()), ids=lambda c: c["name"])
+def test_draft_attention_chain_golden(ops, c):
+    kc, vc = g(c["kc"]).clone(), g(c["vc"]).clone()
+    kc_o, vc_o = c["kc"].clone(), c["vc"].clone()
+    for st in c["steps"]:
+        if st["kind"] == "step0":
+            out = ops.kvcache_attention(g(st["q"]), kc, vc, g(st["k"]), g(st["v"]), cache_seqlens=g(st["cache_lens"]),
+                                        causal=True, window_size=(512, -1), kv_len_hint=c["p"])
+            ref_ops.draft_self_attention_step0(st["q"], st["k"], st["v"], kc_o, vc_o, st["cache_lens"])
+        else:
+            M, N = st["mask"].shape[1:]
+            out = ops.draft_tree_attention(g(st["q"]), g(st["k"]), g(st["v"]), kc, vc, g(st["cache_lens"]),
+                                           ops.pack_tree_mask(g(st["mask"])), N, kv_len_hint=c["p"])
+            ref_ops.draft_tree_self_attention(st["q"], st["k"], st["v"], kc_o, vc_o, st["cache_lens"], st["mask"])
+        assert_close_f16(out, st["out"], atol=1.1e-3, frac=0.03, what=st["kind"])
+        assert torch.equal(kc.cpu(), kc_o) and torch.equal(vc.cpu(), vc_o)
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE sizes: size-independent properties
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("L", [16384, 131072])
+def test_full_size_properties(ops, L):
+    """Llama-3-8B heads at 16k / 128k prefix: (1) LSE-merge of two half-prefix calls ==
+    one full call (the multi-GPU identity); (2) split-count invariance; (3) agreement with a
+    dense fp32 soft-max evaluated on the GPU by torch."""
+    H, Hkv, R = 32, 8, 74
+    gen = torch.Generator(device="cpu").manual_seed(1235)
+    q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 1235)
+    kc = torch.randn(1, L + 128, Hkv, 128, generator=gen).to(torch.float16).to(DEV)
+    vc = torch.randn(1, L + 128, Hkv, 128, generator=gen).to(torch.float16).to(DEV)
+    qg = g(q)
+    cl = torch.tensor([L], dtype=torch.int32, device=DEV)
+    o_full, lse_full = ops.kvcache_attention(qg, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L)
+    # (2)
+    o_s, lse_s = ops.kvcache_attention(qg, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L, n_splits=5)
+    assert (o_full.float() - o_s.float()).abs().max().item() <= 5e-4
+    assert (lse_full - lse_s).abs().max().item() <= 2e-5
+    # (1)
+    h = L // 2 + 13
+    d1 = ops._desc(qg, kc[:, :h], vc[:, :h], torch.tensor([h], dtype=torch.int32, device=DEV), h,
+                   out=torch.empty_like(qg))
+    d2 = ops._desc(qg, kc[:, h:], vc[:, h:], torch.tensor([L - h], dtype=torch.int32, device=DEV), L - h,
+                   out=torch.empty_like(qg))
+    parts = [ops.ShardedAttnCall(d, torch.empty_like(qg), qg.device).partial() for d in (d1, d2)]
+    out, _, lse = ops.lse_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), dtype=torch.float16)
+    assert (out.float() - o_full.float()).abs().max().item() <= 5e-4
+    assert (lse - lse_full).abs().max().item() <= 2e-5
+    # (3) dense fp32 reference on the GPU, 4 heads at a time
+    g_ = H // Hkv
+    for h0 in range(0, H, 8):
+        qh = qg[0, :, h0:h0 + 8].float().permute(1, 0, 2)                              # 8 R D
+        kh = kc[0, :L, h0 // g_:(h0 + 8) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        vh = vc[0, :L, h0 // g_:(h0 + 8) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        s = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(128)
+        ref = torch.matmul(torch.softmax(s, -1), vh).permute(1, 0, 2)
+        assert (o_full[0, :, h0:h0 + 8].float() - ref).abs().max().item() <= 1e-3
+        assert (lse_full[0, h0:h0 + 8] - torch.logsumexp(s, -1)).abs().max().item() <= 1e-4
