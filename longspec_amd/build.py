@@ -19,7 +19,8 @@ LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblongspec_hip.so")
 SOURCES = ["attn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "ls_common.h"), os.path.join(os.path.dirname(HERE), "include", "longspec_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# -ffp-contract=off: the reference-order roundings (fp16 product, fp16 sum) must not be fused into FMAs
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=off"]
 
 
 def _hipcc() -> str:

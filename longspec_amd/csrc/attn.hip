@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
     typename E::V8 qf[QLDS ? 1 : QT][4];
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;          // LDS byte address of the carve
-    const unsigned qbase = smem_a + 2 * BUF + wave * (QT * 16 * ROWB);
+    const unsigned qbase = smem_a + 2 * BUF + rb * (QT * 16 * ROWB);       // shared by the KS waves of a row block
     const LaneTbl tb = make_lane_tbl(l15, g4);
     const bool prescale = is_new && p.new_mode == LS_NEW_TARGET && p.prescale_q;
 #pragma unroll
@@ -273,14 +273,14 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
             }
-            if (QLDS)
-                *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(qbase + qt * 16 * ROWB + tb.k[k4]) = v;
-            else
+            if (QLDS) {
+                if (ks == 0) *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(qbase + qt * 16 * ROWB + tb.k[k4]) = v;
+            } else
                 qf[QLDS ? 0 : qt][k4] = v;
         }
     }
-    // (QLDS: each wave reads back only what it wrote itself; the first __syncthreads() of the
-    //  tile loop orders the ds_write before any ds_read)
+    // (QLDS: the image of a row block is written by its ks == 0 wave; the first __syncthreads()
+    //  of the tile loop orders these ds_writes before any wave's ds_read)
 
     WaveAcc<E, QT> w;
 #pragma unroll
@@ -708,7 +708,7 @@ template <typename E, int RB, int KS, int QT, int TKW>
 int launch_partial(const AttnK& k, dim3 grid, hipStream_t s) {
     constexpr int TILE = KS * TKW;
     const int lds = 2 * (2 * TILE * ROWB)                 // double-buffered (K,V) tiles
-                    + (QT >= 5 ? 4 * QT * 16 * ROWB : 0);  // per-wave Q image
+                    + (QT >= 5 ? RB * QT * 16 * ROWB : 0);  // Q image of each row block
     auto fn = attn_partial_kernel<E, RB, KS, QT, TKW>;
     static bool attr_set = false;
     if (!attr_set) {

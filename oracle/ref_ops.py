@@ -81,6 +81,8 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, vis: Optional[tor
     sk, Hkv, _ = k.shape
     g = H // Hkv
     dt = q.dtype
+    if sk == 0:       # empty key set: zeros and lse = -inf
+        return torch.zeros_like(q), torch.full((H, sq), float("-inf"), dtype=F32)
     qf = q.float().permute(1, 0, 2)                                   # H sq D
     kf = k.float().permute(1, 0, 2).repeat_interleave(g, dim=0)       # H sk D
     vf = v.float().permute(1, 0, 2).repeat_interleave(g, dim=0)

@@ -26,12 +26,17 @@ def g(t):
     return t.to(DEV) if torch.is_tensor(t) else t
 
 
-def assert_close_f16(got, want, atol=1.1e-3, frac=0.02, what=""):
-    """Reference-order restatement parity: at most one fp16 ulp (|o| <~ 2) on a small fraction."""
+def assert_close_f16(got, want, atol=1.1e-3, frac=None, mean=1.5e-4, what=""):
+    """Parity bar of SURVEY 8(d): every element within one fp16 ulp at the output's magnitude
+    (1e-3 abs for |o| <~ 2), mean |diff| an order of magnitude below that; `frac` bounds the
+    share of differing elements where the arithmetic order is pinned (not through the
+    flash-style prefix, whose P -> fp16 rounding depends on the split-local running max)."""
     d = (got.float().cpu() - want.float().cpu()).abs()
     assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
     assert d.max().item() <= atol, f"{what}: max |diff| {d.max().item():.3e} > {atol}"
-    assert (d > 0).float().mean().item() <= frac, f"{what}: {(d > 0).float().mean().item():.3%} elements differ"
+    assert d.mean().item() <= mean, f"{what}: mean |diff| {d.mean().item():.3e} > {mean}"
+    if frac is not None:
+        assert (d > 0).float().mean().item() <= frac, f"{what}: {(d > 0).float().mean().item():.3%} elements differ"
 
 
 # --------------------------------------------------------------------------- #
@@ -41,7 +46,7 @@ def assert_close_f16(got, want, atol=1.1e-3, frac=0.02, what=""):
 def test_rmsnorm_golden(ops, c):
     y = ops.rmsnorm(g(c["x"]), g(c["w"]), c["eps"])
     # fp32 reduction order differs from torch's: allow one fp16 ulp on a sliver of elements
-    assert_close_f16(y, c["y"], atol=4e-3, frac=0.002, what="rmsnorm")
+    assert_close_f16(y, c["y"], atol=4e-3, frac=0.002, mean=1e-5, what="rmsnorm")
 
 
 def test_rmsnorm_residual(ops):
@@ -51,7 +56,7 @@ def test_rmsnorm_residual(ops):
     y, s = ops.rmsnorm(g(x), g(w), 1e-5, residual=g(r))
     s_ref = r + x
     assert torch.equal(s.cpu(), s_ref)
-    assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=8e-3, frac=0.002, what="rmsnorm+res")
+    assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=8e-3, frac=0.002, mean=1e-5, what="rmsnorm+res")
 
 
 @pytest.mark.parametrize("c", list(cases.rope_cases()), ids=lambda c: c["name"])
@@ -244,7 +249,7 @@ def test_bf16_prefix(ops):
     cl = torch.tensor([L], dtype=torch.int32)
     o_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl)
     o = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), kv_len_hint=L)
-    assert_close_f16(o, o_ref, atol=8.5e-3, what="bf16")      # one bf16 ulp at |o| ~ 1
+    assert_close_f16(o, o_ref, atol=8.5e-3, mean=1.2e-3, what="bf16")      # one bf16 ulp at |o| ~ 1
 
 
 # --------------------------------------------------------------------------- #
@@ -257,7 +262,7 @@ def test_verify_attention_golden(ops, c, last_layer):
     bits = ops.pack_tree_mask(g(c["mask"]))
     out = ops.verify_attention(g(c["q"]), g(c["k"]), g(c["v"]), kc, vc, g(c["cache_lens"]), bits, last_layer,
                                kv_len_hint=c["L"])
-    assert_close_f16(out, c["hybrid"][last_layer], atol=2.1e-3, frac=0.05, what="verify")
+    assert_close_f16(out, c["hybrid"][last_layer], atol=2.1e-3, what="verify")
     L = c["L"]
     assert torch.equal(kc[:, L:L + 74].cpu(), c["k"]) and torch.equal(vc[:, L:L + 74].cpu(), c["v"])
     assert torch.equal(kc[:, :L].cpu(), c["kc"][:, :L])
@@ -288,7 +293,7 @@ def test_verify_attention_model_shapes_vs_oracle(ops, H, Hkv):
         kc_g, vc_g = g(kc), g(vc)
         out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), False,
                                    kv_len_hint=4096 + 37)
-        assert_close_f16(out, ref, atol=2.1e-3, frac=0.05, what=f"H={H}")
+        assert_close_f16(out, ref, atol=2.1e-3, what=f"H={H}")
         assert torch.equal(kc_g.cpu(), kc_r)
 
 
@@ -309,7 +314,7 @@ def test_draft_attention_chain_golden(ops, c):
             out = ops.draft_tree_attention(g(st["q"]), g(st["k"]), g(st["v"]), kc, vc, g(st["cache_lens"]),
                                            ops.pack_tree_mask(g(st["mask"])), N, kv_len_hint=c["p"])
             ref_ops.draft_tree_self_attention(st["q"], st["k"], st["v"], kc_o, vc_o, st["cache_lens"], st["mask"])
-        assert_close_f16(out, st["out"], atol=1.1e-3, frac=0.03, what=st["kind"])
+        assert_close_f16(out, st["out"], atol=1.1e-3, what=st["kind"])
         assert torch.equal(kc.cpu(), kc_o) and torch.equal(vc.cpu(), vc_o)
 
 
