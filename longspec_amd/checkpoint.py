@@ -1,0 +1,94 @@
+"""Checkpoint loading in the reference's formats, without the HF ``from_pretrained`` coupling.
+
+* target: a HF Llama directory (``config.json`` + ``*.safetensors`` / ``pytorch_model*.bin``,
+  optionally sharded with an ``*.index.json``), as ``LlamaForCausalLM.from_pretrained`` reads
+  it (``longspec/test/llama_glide.py:474``);
+* draft: the directory ``LlamaGlideDecoderLayer.from_pretrained`` reads (``:480``): 20 tensors
+  ``{self_attn,cross_attn}.{q,k,v}_proj.{weight,bias}``, ``{self_attn,cross_attn}.o_proj.weight``,
+  ``mlp.{gate,up,down}_proj.weight``, ``{input,post_self_attention,post_cross_attention}_layernorm.weight``
+  (SURVEY section 5); also accepts the trainer's ``draft_model_weights.pth`` state dict
+  (``longspec/train/trainer_base_ds_mul_fs_tp.py:49-113``).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict
+
+import torch
+
+DRAFT_TENSORS = (
+    [f"{a}.{p}_proj.{w}" for a in ("self_attn", "cross_attn") for p in ("q", "k", "v") for w in ("weight", "bias")]
+    + [f"{a}.o_proj.weight" for a in ("self_attn", "cross_attn")]
+    + [f"mlp.{p}_proj.weight" for p in ("gate", "up", "down")]
+    + [f"{n}.weight" for n in ("input_layernorm", "post_self_attention_layernorm", "post_cross_attention_layernorm")]
+)
+
+
+def load_config(path: str) -> SimpleNamespace:
+    with open(os.path.join(path, "config.json")) as f:
+        d = json.load(f)
+    d.setdefault("head_dim", d["hidden_size"] // d["num_attention_heads"])
+    d.setdefault("attention_bias", False)
+    d.setdefault("mlp_bias", False)
+    d.setdefault("rope_theta", 10000.0)
+    d.setdefault("rope_scaling", None)
+    d.setdefault("num_key_value_heads", d["num_attention_heads"])
+    return SimpleNamespace(**d)
+
+
+def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """All tensors of a checkpoint directory (or single file)."""
+    files = []
+    if os.path.isfile(path):
+        files = [path]
+    else:
+        for pat in ("*.safetensors", "pytorch_model*.bin", "*.pth", "*.pt"):
+            files = sorted(glob.glob(os.path.join(path, pat)))
+            if files:
+                break
+    if not files:
+        raise FileNotFoundError(f"no checkpoint tensors under {path}")
+    sd: Dict[str, torch.Tensor] = {}
+    for fp in files:
+        if fp.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd.update(load_file(fp))
+        else:
+            sd.update(torch.load(fp, map_location="cpu", weights_only=True))
+    return sd
+
+
+def load_target_checkpoint(model, path: str) -> None:
+    sd = read_state_dict(path)
+    if "lm_head.weight" not in sd and "model.embed_tokens.weight" in sd:      # tied embeddings
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    own = {k for k in model.state_dict() if not k.startswith("glide.")}
+    missing = sorted(own - set(sd))
+    if missing:
+        raise KeyError(f"target checkpoint {path} lacks {missing[:5]}{'...' if len(missing) > 5 else ''}")
+    model.load_state_dict({k: sd[k] for k in own}, strict=False)
+
+
+def load_draft_checkpoint(glide, path: str) -> None:
+    sd = read_state_dict(path)
+    for prefix in ("draft_model.", "glide.", "model."):
+        if any(k.startswith(prefix) for k in sd) and not all(k in sd for k in DRAFT_TENSORS):
+            sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing = [k for k in DRAFT_TENSORS if k not in sd]
+    if missing:
+        raise KeyError(f"draft checkpoint {path} lacks {missing}")
+    glide.load_state_dict({k: sd[k] for k in DRAFT_TENSORS}, strict=True)
+
+
+def save_draft_checkpoint(glide, path: str, config=None) -> None:
+    """Write the draft layer in the reference's directory format (safetensors + config.json)."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    sd = {k: v.detach().cpu().contiguous() for k, v in glide.state_dict().items() if k in DRAFT_TENSORS}
+    save_file(sd, os.path.join(path, "model.safetensors"))
+    if config is not None:
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump({k: v for k, v in vars(config).items() if isinstance(v, (int, float, str, bool, list, dict, type(None)))}, f)

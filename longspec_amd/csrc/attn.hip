@@ -28,6 +28,9 @@
 // one barrier per tile.  The LDS image is XOR-swizzled (applied on the per-lane SOURCE
 // address, the LDS destination of the DMA being lane-linear) so that both the
 // ds_read_b128 K-fragment reads and the transposing V reads are bank-conflict free.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "ls_common.h"
 
 namespace {
@@ -54,6 +57,7 @@ struct AttnK {
     int has_new, new_mode, n_new, n_new_cached, mask_words, scatter_new, prescale_q;
     int causal, window_left, n_app;
     int n_splits, row_chunks, rows_per_chunk;
+    int debug;        // LS_DEBUG experiments: 1 = skip compute, 2 = skip DMA
     float scale;
     long q_sb, q_ss, q_sh;
     long kc_sb, kc_ss, kc_sh;
@@ -153,27 +157,40 @@ __device__ __forceinline__ void pv_block(WaveAcc<E, QT>& w, const typename E::V8
     }
 }
 
-// Online soft-max update (base-2 exponentials) for one 32-key block whose masked scores are
-// already -inf, then P.V.
-template <typename E, int QT>
+// Soft-max update (base-2 exponentials) for one 32-key block whose masked scores are already
+// -inf, then P.V.
+//   SAFE = true : textbook online soft-max -- block row-max, running max m, rescale of O and l
+//                 whenever a row's max grows.
+//   SAFE = false: the running max is used as a FIXED reference: p = 2^(s*c - m*c) without looking
+//                 at the block's own max, so the 160 accumulator registers are touched by MFMAs
+//                 only.  Exact as long as no p overflows fp16 (s - m < ~11 in natural-log units,
+//                 i.e. a key scoring e^11 above everything seen so far); the largest p is tracked
+//                 in `pmax` and the caller re-runs the split with SAFE = true if it ever gets
+//                 near the fp16 range.  (lse = m*scale + ln(l) holds for any reference m.)
+template <typename E, int QT, bool SAFE>
 __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], float c, const LaneTbl& tb,
-                                             unsigned vbase) {
+                                             unsigned vbase, float& pmax) {
     typename E::V8 pf[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                         fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-        mx = wave_xor_max_16_32(mx);
-        const float m_new = fmaxf(w.m[qt], mx);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;     // row with no visible key so far
-        if (__any(m_new > w.m[qt])) {
-            const float alpha = __builtin_amdgcn_exp2f((w.m[qt] - m_safe) * c);
-            w.l[qt] *= alpha;
+        float mc;
+        if (SAFE) {
+            float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                             fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+            mx = wave_xor_max_16_32(mx);
+            const float m_new = fmaxf(w.m[qt], mx);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;     // row with no visible key so far
+            if (__any(m_new > w.m[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f((w.m[qt] - m_safe) * c);
+                w.l[qt] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] *= alpha;
-            w.m[qt] = m_new;
+                for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] *= alpha;
+                w.m[qt] = m_new;
+            }
+            mc = m_safe * c;
+        } else {
+            mc = w.m[qt] * c;
         }
-        const float mc = m_safe * c;
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -181,6 +198,7 @@ __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)
             for (int e = 0; e < 4; ++e) {
                 const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
                 ps += pe;
+                if (!SAFE) pmax = fmaxf(pmax, pe);
                 pf[qt][kt * 4 + e] = E::from_f32(pe);
             }
         w.l[qt] += ps;
@@ -210,37 +228,105 @@ __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int l
 }
 
 // ---- the kernel -----------------------------------------------------------------------
+// Common per-wave setup, shared by the two paths below.
 template <typename E, int RB, int KS, int QT, int TKW>
-__global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
-    constexpr int TILE = KS * TKW;            // keys per workgroup iteration
-    constexpr int BUF = 2 * TILE * ROWB;      // bytes of one (K,V) buffer
-    constexpr bool QLDS = QT >= 5;            // Q^T fragments in LDS instead of registers
-    static_assert(RB * KS == 4, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [2 x (K tile, V tile)] [per-wave Q image (QLDS only)]
+struct Ctx {
+    static constexpr int TILE = KS * TKW;            // keys per workgroup iteration
+    static constexpr int BUF = 2 * TILE * ROWB;      // bytes of one (K,V) buffer
+    static constexpr bool QLDS = QT >= 5;            // Q^T fragments in LDS instead of registers
+    int tid, lane, wave, rb, ks, l15, g4, bi, kvh, chunk, L, sk, row0;
+    float c;
+    int rrow[QT];
+    unsigned smem_a, qbase;
+    LaneTbl tb;
+    const char* kc_base;
+    const char* vc_base;
+    long kc_row;
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = wave / KS, ks = wave % KS;
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int bi = blockIdx.z;
-    const int kvh = blockIdx.y % p.Hkv;
-    const int chunk = blockIdx.y / p.Hkv;
-    const bool is_new = p.has_new && blockIdx.x == 0;
-    const int split = (int)blockIdx.x - p.has_new;
-    const int L = p.cache_seqlens[bi];
-    const float c = p.scale * LOG2E;
-    const int sk = L + p.n_app;
-
-    // ---- rows of this wave: lane l15 of q-tile qt owns row m = row0 + qt*16 + l15 -----------
-    const int row0 = chunk * p.rows_per_chunk + rb * QT * 16;
-    int rrow[QT];                 // query row r in [0,sq) (0 for padding rows: computed, never stored)
+template <typename E, int RB, int KS, int QT, int TKW>
+__device__ __forceinline__ void ctx_init(Ctx<E, RB, KS, QT, TKW>& x, const AttnK& p, char* smem) {
+    using C = Ctx<E, RB, KS, QT, TKW>;
+    x.tid = threadIdx.x;
+    x.lane = x.tid & 63;
+    x.wave = __builtin_amdgcn_readfirstlane(x.tid >> 6);
+    x.rb = x.wave / KS;
+    x.ks = x.wave % KS;
+    x.l15 = x.lane & 15;
+    x.g4 = x.lane >> 4;
+    x.bi = blockIdx.z;
+    x.kvh = blockIdx.y % p.Hkv;
+    x.chunk = blockIdx.y / p.Hkv;
+    x.L = p.cache_seqlens[x.bi];
+    x.c = p.scale * LOG2E;
+    x.sk = x.L + p.n_app;
+    // rows of this wave: lane l15 of q-tile qt owns row m = row0 + qt*16 + l15
+    x.row0 = x.chunk * p.rows_per_chunk + x.rb * QT * 16;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        rrow[qt] = m < p.M ? m % p.sq : 0;
+        const int m = x.row0 + qt * 16 + x.l15;
+        x.rrow[qt] = m < p.M ? m % p.sq : 0;     // 0 for padding rows: computed, never stored
     }
+    typedef __attribute__((address_space(3))) char lds_char;
+    x.smem_a = (unsigned)(uintptr_t)(lds_char*)smem;          // LDS byte address of the carve
+    // LDS: [2 x (K tile, V tile)] [Q image of each row block (QLDS only)]
+    x.qbase = x.smem_a + 2 * C::BUF + x.rb * (QT * 16 * ROWB);
+    x.tb = make_lane_tbl(x.l15, x.g4);
+    x.kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)x.bi * p.kc_sb + (long)x.kvh * p.kc_sh) * 2;
+    x.vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)x.bi * p.kc_sb + (long)x.kvh * p.kc_sh) * 2;
+    x.kc_row = p.kc_ss * 2;
+}
+
+// Q^T fragments (B operand of the first product): registers, or the row block's LDS image.
+template <typename E, int RB, int KS, int QT, int TKW>
+__device__ __forceinline__ void load_q(const Ctx<E, RB, KS, QT, TKW>& x, const AttnK& p, bool prescale,
+                                       typename E::V8 (&qf)[(QT >= 5) ? 1 : QT][4]) {
+    constexpr bool QLDS = QT >= 5;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = x.row0 + qt * 16 + x.l15;
+        const int head = x.kvh * p.g + (m < p.M ? m / p.sq : 0);
+        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)x.bi * p.q_sb +
+                                  (long)x.rrow[qt] * p.q_ss + (long)head * p.q_sh + x.g4 * 8;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            typename E::V8 v = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+            if (prescale) {   // `query_states * self.softmax_scale` in the activation dtype (llama.py:407)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
+            }
+            if (QLDS) {
+                // the image of a row block is written by its ks == 0 wave; the first __syncthreads()
+                // of the tile loop orders these ds_writes before any wave's ds_read
+                if (x.ks == 0)
+                    *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(x.qbase + qt * 16 * ROWB + x.tb.k[k4]) = v;
+            } else {
+                qf[QLDS ? 0 : qt][k4] = v;
+            }
+        }
+    }
+}
+
+template <typename E, int QT>
+__device__ __forceinline__ void acc_init(WaveAcc<E, QT>& w) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        w.m[qt] = -INFINITY;
+        w.l[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ================= prefix split: tiles [t_begin, t_end) of TILE keys =====================
+template <typename E, int RB, int KS, int QT, int TKW>
+__device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int split) {
+    using C = Ctx<E, RB, KS, QT, TKW>;
+    constexpr int TILE = C::TILE, BUF = C::BUF;
+    constexpr bool QLDS = C::QLDS;
+    C x;
+    ctx_init(x, p, smem);
+    const int L = x.L, sk = x.sk, l15 = x.l15, g4 = x.g4;
     // visible prefix key range of row r (flash-attn bottom-right alignment):
     //   lo(r) = max(0, r + sk - sq - window_left), hi(r) = min(L, r + sk - sq + 1) if causal else L
     int lo_min = 0, lo_max = 0, hi_min = L, hi_max = L;
@@ -252,83 +338,51 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
         hi_min = max(0, min(L, sk - p.sq + 1));
         hi_max = max(0, min(L, sk));
     }
-
-    // ---- Q^T fragments (B operand of the first product) ------------------------------
     typename E::V8 qf[QLDS ? 1 : QT][4];
-    typedef __attribute__((address_space(3))) char lds_char;
-    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;          // LDS byte address of the carve
-    const unsigned qbase = smem_a + 2 * BUF + rb * (QT * 16 * ROWB);       // shared by the KS waves of a row block
-    const LaneTbl tb = make_lane_tbl(l15, g4);
-    const bool prescale = is_new && p.new_mode == LS_NEW_TARGET && p.prescale_q;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
-        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb +
-                                  (long)rrow[qt] * p.q_ss + (long)head * p.q_sh + g4 * 8;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            typename E::V8 v = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
-            if (prescale) {   // `query_states * self.softmax_scale` in the activation dtype (llama.py:407)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
-            }
-            if (QLDS) {
-                if (ks == 0) *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(qbase + qt * 16 * ROWB + tb.k[k4]) = v;
-            } else
-                qf[QLDS ? 0 : qt][k4] = v;
-        }
-    }
-    // (QLDS: the image of a row block is written by its ks == 0 wave; the first __syncthreads()
-    //  of the tile loop orders these ds_writes before any wave's ds_read)
-
+    load_q<E, RB, KS, QT, TKW>(x, p, false, qf);
     WaveAcc<E, QT> w;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        w.m[qt] = -INFINITY;
-        w.l[qt] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
 
-    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const long kc_row = p.kc_ss * 2;
-
-    if (!is_new) {
-        // ================= prefix split: tiles [t_begin, t_end) of TILE keys =================
-        const int t0 = lo_min / TILE;
-        const int t1 = (hi_max + TILE - 1) / TILE;
-        const int tps = (max(t1 - t0, 0) + p.n_splits - 1) / p.n_splits;
-        const int t_begin = t0 + split * tps;
-        const int t_end = min(t_begin + tps, t1);
-        const int last_key = hi_max - 1;
-        auto dma = [&](int tile, int buf) {
-            char* bK = smem + buf * BUF;
-            tile_dma<TILE>(bK, bK + TILE * ROWB, wave, lane, [&](int key, const char*& kp, const char*& vp) {
-                const long ka = min(tile * TILE + key, last_key);   // tail rows: re-read the last valid key (masked below)
-                kp = kc_base + ka * kc_row;
-                vp = vc_base + ka * kc_row;
-            });
-        };
-        if (t_begin < t_end) dma(t_begin, 0);
-        for (int t = t_begin; t < t_end; ++t) {
+    const int t0 = lo_min / TILE;
+    const int t1 = (hi_max + TILE - 1) / TILE;
+    const int tps = (max(t1 - t0, 0) + p.n_splits - 1) / p.n_splits;
+    const int t_begin = t0 + split * tps;
+    const int t_end = min(t_begin + tps, t1);
+    const int last_key = hi_max - 1;
+    auto dma = [&](int tile, int buf) {
+        char* bK = smem + buf * BUF;
+        tile_dma<TILE>(bK, bK + TILE * ROWB, x.wave, x.lane, [&](int key, const char*& kp, const char*& vp) {
+            const long ka = min(tile * TILE + key, last_key);   // tail rows: re-read the last valid key (masked below)
+            kp = x.kc_base + ka * x.kc_row;
+            vp = x.vc_base + ka * x.kc_row;
+        });
+    };
+    // Three tile ranges share one DMA pipeline:  [t_begin, tA) and [tB, t_end) touch a range edge
+    // (window / causal / tail of the cache) or prime the running max and run the textbook online
+    // soft-max with masks; [tA, tB) are interior tiles and run the fixed-reference form whose loop
+    // body is branch-free: DMA issue, barrier, 2 x (QK^T, exp2, P.V).
+    // attempt 1 (only if some p came close to the fp16 range): textbook form everywhere.
+    int* redo_flag = reinterpret_cast<int*>(smem + 2 * BUF + (QLDS ? RB * QT * 16 * ROWB : 0));
+    float pmax = 0.f;
+    auto run_tiles = [&](int t_from, int t_to, auto safe_tag) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        for (int t = t_from; t < t_to; ++t) {
             const int buf = (t - t_begin) & 1;
             __syncthreads();                      // tile t landed (vmcnt(0) + barrier); buffer buf^1 is free
-            if (t + 1 < t_end) dma(t + 1, buf ^ 1);
-            const unsigned kb_a = smem_a + buf * BUF;               // K tile, V tile follows at + TILE*ROWB
-#pragma unroll 1
+            if (t + 1 < t_end && !(p.debug & 2)) dma(t + 1, buf ^ 1);
+            const unsigned kb_a = x.smem_a + buf * BUF;               // K tile, V tile follows at + TILE*ROWB
+            if (p.debug & 1) continue;
+#pragma unroll
             for (int blk = 0; blk < TKW / 32; ++blk) {
-                const int krow0 = ks * TKW + blk * 32;
+                const int krow0 = x.ks * TKW + blk * 32;
                 const int ka0 = t * TILE + krow0;
-                if (ka0 >= hi_max || ka0 + 32 <= lo_min) continue;   // wave-uniform
+                if (SAFE && (ka0 >= hi_max || ka0 + 32 <= lo_min)) continue;   // wave-uniform
                 f32x4 s[2][QT];
-                qk_block<E, QT, QLDS>(s, qf, tb, qbase, kb_a + krow0 * ROWB);
-                if (!(ka0 >= lo_max && ka0 + 32 <= hi_min)) {        // block touches a range edge
+                qk_block<E, QT, QLDS>(s, qf, x.tb, x.qbase, kb_a + krow0 * ROWB);
+                if (SAFE && !(ka0 >= lo_max && ka0 + 32 <= hi_min)) {          // block touches a range edge
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        const int lo = p.window_left >= 0 ? max(0, rrow[qt] + sk - p.sq - p.window_left) : 0;
-                        const int hi = p.causal ? min(L, rrow[qt] + sk - p.sq + 1) : L;
+                        const int lo = p.window_left >= 0 ? max(0, x.rrow[qt] + sk - p.sq - p.window_left) : 0;
+                        const int hi = p.causal ? min(L, x.rrow[qt] + sk - p.sq + 1) : L;
 #pragma unroll
                         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -338,29 +392,75 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
                             }
                     }
                 }
-                online_block<E, QT>(w, s, c, tb, kb_a + (TILE + krow0) * ROWB);
+                online_block<E, QT, SAFE>(w, s, x.c, x.tb, kb_a + (TILE + krow0) * ROWB, pmax);
             }
         }
-        // ---- write the (normalised) partial ------------------------------------------
-        const int part = split * KS + ks;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float lt = wave_xor_sum_16_32(w.l[qt]);
-            const float inv = lt > 0.f ? 1.f / lt : 0.f;
-            const float lse = lt > 0.f ? w.m[qt] * p.scale + __logf(lt) : -INFINITY;
-            const int m = row0 + qt * 16 + l15;
-            if (m < p.M) {
-                const int head = kvh * p.g + m / p.sq;
-                float* op = p.parts_o + ((((long)part * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = w.acc[dt][qt] * inv;
-                if (g4 == 0) p.parts_lse[(((long)part * p.b + bi) * p.H + head) * p.sq + rrow[qt]] = lse;
-            }
-        }
-        return;
+    };
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        acc_init<E, QT>(w);
+        pmax = 0.f;
+        if (x.tid == 0) *redo_flag = 0;
+        if (t_begin < t_end) dma(t_begin, 0);
+        // interior tiles: whole tile inside [lo_max, hi_min); the first tile always primes the max
+        int tA = max(t_begin + 1, (lo_max + TILE - 1) / TILE);
+        int tB = min(t_end, hi_min / TILE);
+        if (attempt == 1 || tB < tA) tA = tB = t_end;
+        run_tiles(t_begin, tA, std::true_type{});
+        run_tiles(tA, tB, std::false_type{});
+        run_tiles(tB, t_end, std::true_type{});
+        if (attempt == 1) break;
+        if (__any(pmax > 16384.f) && x.lane == 0) *redo_flag = 1;     // 2^14: two octaves below fp16 max
+        __syncthreads();
+        const int redo = *redo_flag;
+        __syncthreads();
+        if (!redo) break;
     }
+    // ---- write the (normalised) partial ------------------------------------------
+    const int part = split * KS + x.ks;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float lt = wave_xor_sum_16_32(w.l[qt]);
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const float lse = lt > 0.f ? w.m[qt] * p.scale + __logf(lt) : -INFINITY;
+        const int m = x.row0 + qt * 16 + l15;
+        if (m < p.M) {
+            const int head = x.kvh * p.g + m / p.sq;
+            float* op = p.parts_o + ((((long)part * p.b + x.bi) * p.sq + x.rrow[qt]) * p.H + head) * D + g4 * 4;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = w.acc[dt][qt] * inv;
+            if (g4 == 0) p.parts_lse[(((long)part * p.b + x.bi) * p.H + head) * p.sq + x.rrow[qt]] = lse;
+        }
+    }
+}
 
-    // ===================== new key block (tree / appended tokens) ===========================
+// ===================== new key block (tree / appended tokens) ===========================
+// Kept out of line: a handful of workgroups run it once per launch, and its three
+// numerics variants must not weigh on the register allocation of the streaming loop above.
+template <typename E, int RB, int KS, int QT, int TKW>
+__device__ __attribute__((noinline)) void new_block_path(const AttnK p, char* smem) {
+    // (by value: the caller's copy lives on the cold branch only, so the streaming path keeps
+    //  its parameters in scalar registers)
+    using C = Ctx<E, RB, KS, QT, TKW>;
+    constexpr int TILE = C::TILE;
+    constexpr bool QLDS = C::QLDS;
+    C x;
+    ctx_init(x, p, smem);
+    const int L = x.L, l15 = x.l15, g4 = x.g4, tid = x.tid, bi = x.bi, kvh = x.kvh;
+    const float c = x.c;
+    typename E::V8 qf[QLDS ? 1 : QT][4];
+    load_q<E, RB, KS, QT, TKW>(x, p, p.new_mode == LS_NEW_TARGET && p.prescale_q, qf);
+    WaveAcc<E, QT> w;
+    acc_init<E, QT>(w);
+    const char* kc_base = x.kc_base;
+    const char* vc_base = x.vc_base;
+    const long kc_row = x.kc_row;
+    const int row0 = x.row0;
+    const int chunk = x.chunk;
+    const int ks = x.ks;
+    const int (&rrow)[QT] = x.rrow;
+    const LaneTbl& tb = x.tb;
+    const unsigned smem_a = x.smem_a, qbase = x.qbase;
+    const int wave = x.wave, lane = x.lane;
     const int n_new = p.n_new;
     const int nblk = (n_new + 31) / 32;
     const char* kn_base = reinterpret_cast<const char*>(p.k_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
@@ -382,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
 
     const bool worker = (ks == 0);   // the few new keys are not split across waves
     const int npass = (p.new_mode == LS_NEW_TARGET) ? 3 : 1;
+    float pmax_unused = 0.f;
     float tmax[QT], tsum[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -425,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 if (!((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u)) s[kt][qt][e] = -INFINITY;
-                    online_block<E, QT>(w, s, c, tb, smem_a + (TILE + krow0) * ROWB);
+                    online_block<E, QT, true>(w, s, c, tb, smem_a + (TILE + krow0) * ROWB, pmax_unused);
                     continue;
                 }
                 // ---- LlamaAttention.tree_part_fwd numerics (llama.py:406-415): the QK^T result is
@@ -506,6 +607,16 @@ __global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
             if (g4 == 0) p.new_lse[((long)bi * p.H + head) * p.sq + rrow[qt]] = lse;
         }
     }
+}
+
+template <typename E, int RB, int KS, int QT, int TKW>
+__global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
+    static_assert(RB * KS == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.has_new && blockIdx.x == 0)
+        new_block_path<E, RB, KS, QT, TKW>(p, smem);
+    else
+        prefix_path<E, RB, KS, QT, TKW>(p, smem, (int)blockIdx.x - p.has_new);
 }
 
 // ---- stage 2: combine + merge ----------------------------------------------------------
@@ -627,7 +738,7 @@ Cfg pick_cfg(int M) {
     } else if (M <= 320) {
         c = Cfg{4, 1, 5, 64, 1, 0};
     } else if (M <= 384) {
-        c = Cfg{4, 1, 6, 64, 1, 0};
+        c = Cfg{4, 1, 6, 32, 1, 0};      // 32-key tiles: 96 KB of Q image + 32 KB of K/V buffers
     } else {
         c = Cfg{4, 1, 5, 64, (M + 319) / 320, 0};
     }
@@ -708,7 +819,8 @@ template <typename E, int RB, int KS, int QT, int TKW>
 int launch_partial(const AttnK& k, dim3 grid, hipStream_t s) {
     constexpr int TILE = KS * TKW;
     const int lds = 2 * (2 * TILE * ROWB)                 // double-buffered (K,V) tiles
-                    + (QT >= 5 ? RB * QT * 16 * ROWB : 0);  // Q image of each row block
+                    + (QT >= 5 ? RB * QT * 16 * ROWB : 0)   // Q image of each row block
+                    + 16;                                   // redo flag
     auto fn = attn_partial_kernel<E, RB, KS, QT, TKW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -735,7 +847,7 @@ int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
     } else if (c.RB == 4 && c.KS == 1 && c.QT == 5) {
         return launch_partial<E, 4, 1, 5, 64>(k, grid, s);
     } else if (c.RB == 4 && c.KS == 1 && c.QT == 6) {
-        return launch_partial<E, 4, 1, 6, 64>(k, grid, s);
+        return launch_partial<E, 4, 1, 6, 32>(k, grid, s);
     }
     LS_FAIL(LS_ERR_UNSUPPORTED, "no kernel for RB=%d KS=%d QT=%d", c.RB, c.KS, c.QT);
 }
@@ -778,6 +890,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.row_chunks = c.row_chunks;
     k.rows_per_chunk = c.rows_per_chunk;
     k.scale = d->softmax_scale;
+    { const char* e = getenv("LS_DEBUG"); k.debug = e ? atoi(e) : 0; }
     k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
     k.kn_sb = d->kn_stride_b; k.kn_ss = d->kn_stride_s; k.kn_sh = d->kn_stride_h;

@@ -1,0 +1,249 @@
+"""Target model with exec-type dispatch -- host-side mirror of ``longspec/test/llama.py``.
+
+Same module tree, attribute names (``model.layers[i].self_attn.{K_Cache,V_Cache}``,
+``model.embed_tokens``, ``model.rotary_emb``, ``model.norm``, ``lm_head``), call signatures
+and KV-cache layout (``[bsz, prompt + max_len, Hkv, D]`` token-major, zero-initialised,
+``llama.py:219-222``) as the reference, so ``LlamaGlide`` below it reads like the
+reference's.  Every attention / norm / rotary operator goes through ``longspec_amd.ops``
+(hand-written HIP kernels behind the C ABI); dense projections are plain ``F.linear``
+(hipBLASLt through PyTorch-ROCm).
+
+``ops`` is injectable so that the CPU test-suite can drive this host logic with the oracle's
+operators; the product default is the HIP operator layer, which raises on CPU tensors.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _default_ops():
+    from . import ops
+    return ops
+
+
+# --------------------------------------------------------------------------- #
+# rotary embedding
+# --------------------------------------------------------------------------- #
+def rope_parameters(config):
+    """(inv_freq fp32 [D/2], attention_scaling) for the RoPE variants of BASELINE's models:
+    'default' (Llama-3-8B-262k theta=283461213, QwQ theta=1e6) and 'linear' (Vicuna-16k x4,
+    LongChat x8) -- transformers ``ROPE_INIT_FUNCTIONS`` semantics."""
+    dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+    rp = getattr(config, "rope_parameters", None) or {}
+    scaling = getattr(config, "rope_scaling", None) or {}
+    theta = rp.get("rope_theta", getattr(config, "rope_theta", 10000.0))
+    rtype = rp.get("rope_type", scaling.get("rope_type", scaling.get("type", "default")))
+    factor = rp.get("factor", scaling.get("factor", 1.0))
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim))
+    if rtype == "linear":
+        inv_freq = inv_freq / factor
+    elif rtype != "default":
+        raise NotImplementedError(f"rope_type {rtype!r}")
+    return inv_freq, 1.0
+
+
+class LlamaRotaryEmbedding(nn.Module):
+    """``LlamaRotaryEmbedding.forward`` (transformers; K9): cos/sin tables in the activation dtype."""
+
+    def __init__(self, config, ops=None):
+        super().__init__()
+        # plain attribute, not a buffer: model.half() must not round inv_freq to fp16
+        self.inv_freq, self.attention_scaling = rope_parameters(config)
+        self.ops = ops
+
+    @torch.no_grad()
+    def forward(self, x, position_ids):
+        if self.inv_freq.device != x.device:
+            self.inv_freq = self.inv_freq.to(x.device)
+        return self.ops.rope_cos_sin(position_ids, self.inv_freq, self.attention_scaling, x.dtype)
+
+
+class LlamaRMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6, ops=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+        self.ops = ops
+
+    def forward(self, hidden_states):
+        return self.ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        bias = getattr(config, "mlp_bias", False)
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=bias)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+def chunked_causal_prefill(ops, q, k, v, k_cache, v_cache, window_left=-1):
+    """Prompt attention (K13, ``flash_attn_func(causal=True[, window_size=(512,-1)])``,
+    ``llama.py:218`` / ``llama_glide.py:227``) + cache fill, delegated to the operator layer."""
+    return ops.prefill_attention(q, k, v, k_cache, v_cache, window_left=window_left)
+
+
+class LlamaAttention(nn.Module):
+    """``LlamaAttention`` (``longspec/test/llama.py:55-421``): prefill / decoding / tree_decoding."""
+
+    def __init__(self, config, layer_idx: int, ops=None):
+        super().__init__()
+        self.config = config
+        self.layer_idx = layer_idx
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        bias = getattr(config, "attention_bias", False)
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.K_Cache = None
+        self.V_Cache = None
+        self.max_len = 512
+        self.last_layer = (config.num_hidden_layers == layer_idx + 1)
+        self.softmax_scale = 1 / (128 ** 0.5)          # hard-coded in the reference (llama.py:95, G1)
+        self.ops = ops
+        self.kv_len_hint = None                          # host-side upper bound of cache_lens (grid sizing)
+
+    def _qkv(self, hidden_states, position_embeddings):
+        bsz, q_len, _ = hidden_states.size()
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        cos, sin = position_embeddings
+        self.ops.rope_apply_(q, k, cos, sin)
+        return q, k, v
+
+    def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, tree_mask=None,
+                exec_type="training", induction_head=False, tree_mask_bits=None):
+        if exec_type == "prefill":
+            y = self.prefill(hidden_states, position_embeddings)
+        elif exec_type == "decoding":
+            y = self.decoding(hidden_states, position_embeddings, cache_lens)
+        elif exec_type == "tree_decoding":
+            y = self.tree_decoding(hidden_states, position_embeddings, cache_lens, tree_mask, tree_mask_bits)
+        else:
+            raise ValueError(f"Unknown inference_type: {exec_type}")
+        return y, None
+
+    def prefill(self, hidden_states, position_embeddings):          # llama.py:199-226
+        bsz, q_len, _ = hidden_states.size()
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        self.K_Cache = q.new_zeros((bsz, q_len + self.max_len, self.num_key_value_heads, self.head_dim))
+        self.V_Cache = q.new_zeros((bsz, q_len + self.max_len, self.num_key_value_heads, self.head_dim))
+        attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache)
+        return self.o_proj(attn.reshape(bsz, q_len, -1))
+
+    def decoding(self, hidden_states, position_embeddings, cache_lens):   # llama.py:304-329
+        bsz, q_len, _ = hidden_states.size()
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        attn = self.ops.kvcache_attention(q, self.K_Cache, self.V_Cache, k, v, causal=True, cache_seqlens=cache_lens,
+                                          kv_len_hint=self.kv_len_hint)
+        return self.o_proj(attn.view(bsz, q_len, self.hidden_size))
+
+    def tree_decoding(self, hidden_states, position_embeddings, cache_lens, tree_mask=None, tree_mask_bits=None):
+        """llama.py:357-392: prefix flash-decoding + tree part + fp16 merge, one fused op."""
+        bsz, q_len, _ = hidden_states.size()
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        if tree_mask is None and tree_mask_bits is None:
+            assert q_len == 1, "You are in the first step of tree decoding, thus you should not input qlen > 2 without tree mask"
+            attn = self.ops.kvcache_attention(q, self.K_Cache, self.V_Cache, k, v, cache_seqlens=cache_lens, causal=True,
+                                              kv_len_hint=self.kv_len_hint)
+        else:
+            if tree_mask_bits is None:
+                tree_mask_bits = self.ops.pack_tree_mask(tree_mask)
+            attn = self.ops.verify_attention(q, k, v, self.K_Cache, self.V_Cache, cache_lens, tree_mask_bits,
+                                             self.last_layer, softmax_scale=self.softmax_scale,
+                                             kv_len_hint=self.kv_len_hint)
+        return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, config, layer_idx: int, ops=None):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = LlamaAttention(config, layer_idx, ops=ops)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
+
+    def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, exec_type=None, tree_mask=None,
+                induction_head=False, tree_mask_bits=None):
+        residual = hidden_states
+        hidden_states = self.input_layernorm(hidden_states)
+        hidden_states, kv_cache = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                                 cache_lens=cache_lens, exec_type=exec_type, tree_mask=tree_mask,
+                                                 tree_mask_bits=tree_mask_bits)
+        hidden_states = residual + hidden_states
+        residual = hidden_states
+        hidden_states = self.post_attention_layernorm(hidden_states)
+        hidden_states = self.mlp(hidden_states)
+        hidden_states = residual + hidden_states
+        return hidden_states, kv_cache
+
+
+class LlamaModel(nn.Module):
+    def __init__(self, config, ops=None):
+        super().__init__()
+        self.config = config
+        self.ops = ops
+        self.padding_idx = getattr(config, "pad_token_id", None)
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, i, ops=ops) for i in range(config.num_hidden_layers)])
+        self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
+        self.rotary_emb = LlamaRotaryEmbedding(config, ops=ops)
+
+    def forward(self, input_ids, position_ids=None, position_embeddings=None, inputs_embeds=None, cache_lens=None,
+                flex_attn=None, exec_type=None, tree_mask=None, induction_head=False):
+        tree_mask_bits = None
+        if position_ids is None:                                    # llama.py:571-577
+            if tree_mask is None:
+                position_ids = torch.arange(0, input_ids.size(1), device=input_ids.device)[None, :]
+                if cache_lens is not None:
+                    position_ids = position_ids + cache_lens[:, None]
+            else:
+                position_ids = self.ops.tree_positions(tree_mask, cache_lens)
+        if tree_mask is not None:
+            tree_mask_bits = self.ops.pack_tree_mask(tree_mask)     # once per pass, shared by all layers
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        hidden_states = inputs_embeds
+        if position_embeddings is None:
+            position_embeddings = self.rotary_emb(hidden_states, position_ids)
+        for decoder_layer in self.layers:
+            hidden_states, _ = decoder_layer(hidden_states, position_embeddings, cache_lens, flex_attn, exec_type,
+                                             tree_mask, induction_head, tree_mask_bits=tree_mask_bits)
+        hidden_states = self.norm(hidden_states)
+        return SimpleNamespace(last_hidden_state=hidden_states, past_key_values=None)
+
+    def set_kv_len_hint(self, hint: Optional[int]):
+        for layer in self.layers:
+            layer.self_attn.kv_len_hint = hint
+
+
+class LlamaForCausalLM(nn.Module):
+    def __init__(self, config, ops=None):
+        super().__init__()
+        self.config = config
+        self.ops = ops if ops is not None else _default_ops()
+        self.model = LlamaModel(config, ops=self.ops)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    def set_max_gen_len(self, max_gen_len):                          # llama.py:646-648
+        for layer in self.model.layers:
+            layer.self_attn.max_len = max_gen_len

@@ -1,0 +1,494 @@
+"""Draft ("glide") layer and the speculative-decoding loops -- host-side mirror of
+``longspec/test/llama_glide.py``: same classes, method names, argument meaning and
+return tuples, same draft-checkpoint tensor names (20 tensors, q/k/v with
+bias), driven by the HIP operator layer.
+
+Differences from the reference that are deliberate and invisible to callers:
+* every attention / norm / rotary / tree-collapse operator is a hand-written HIP kernel
+  (``longspec_amd.ops``); there is no flash-attn, Triton or torch.compile dependency;
+* the round loop reads ONE scalar per round from the device (``acc_num``) instead of the
+  reference's several implicit synchronisations (``llama_glide.py:1069-1089,1118-1121,1149``);
+* the host keeps an upper bound of every cache length so kernels can size their grids
+  without reading device memory.
+"""
+from __future__ import annotations
+
+import time
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .llama import LlamaForCausalLM, LlamaMLP, LlamaRMSNorm, LlamaRotaryEmbedding, chunked_causal_prefill, _default_ops
+
+
+class GlideAttention(nn.Module):
+    """``GlideAttention`` (``llama_glide.py:23-385``): draft self-attention with a sliding
+    window of 512 over its own KV cache, and cross-attention over the target's last-layer KV."""
+
+    WINDOW = 512
+
+    def __init__(self, config, layer_idx: Optional[int] = None, ops=None):
+        super().__init__()
+        self.config = config
+        self.layer_idx = layer_idx
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=True)     # bias=True even for Llama (:49-52)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.K_Cache = None
+        self.V_Cache = None
+        self.max_len = 512
+        self.softmax_scale = 1 / (self.head_dim ** 0.5)
+        self.ops = ops
+        self.kv_len_hint = None          # bound of the draft cache length
+        self.llm_kv_len_hint = None      # bound of the target last-layer KV length
+
+    def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, exec_type="training",
+                k_cache=None, v_cache=None, llm_kv_len=None, tree_mask=None, tree_mask_bits=None):
+        if exec_type in ["prefill", "sa_prefill"]:
+            y = self.prefill(hidden_states, position_embeddings)
+        elif exec_type == "sa_decoding":
+            y = self.decoding(hidden_states, position_embeddings, cache_lens, K_Cache=None, V_Cache=None)
+        elif exec_type in ["decoding", "ca_decoding", "ca_prefill"]:
+            y = self.decoding(hidden_states, position_embeddings, cache_lens, k_cache, v_cache, llm_kv_len)
+        elif exec_type in ["sa_tree_decoding"]:
+            y = self.tree_decoding(hidden_states, position_embeddings, cache_lens, None, None, llm_kv_len, tree_mask, tree_mask_bits)
+        elif exec_type in ["ca_tree_decoding"]:
+            y = self.tree_decoding(hidden_states, position_embeddings, cache_lens, k_cache, v_cache, llm_kv_len, tree_mask, tree_mask_bits)
+        else:
+            raise ValueError(f"Unknown inference_type: {exec_type}")
+        return y
+
+    def _qkv(self, hidden_states, position_embeddings, need_kv=True):
+        bsz, q_len, _ = hidden_states.size()
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+        cos, sin = position_embeddings
+        if need_kv:
+            k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            self.ops.rope_apply_(q, k, cos, sin)
+            return q, k, v
+        # cross-attention: the reference projects k/v it never uses (:248-249 vs :265); skip them
+        self.ops.rope_apply_(q, q[:, :, :0], cos, sin)
+        return q, None, None
+
+    def prefill(self, hidden_states, position_embeddings):                      # :206-233
+        bsz, q_len, _ = hidden_states.size()
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        self.K_Cache = q.new_zeros((bsz, q_len + self.max_len + 128, self.num_key_value_heads, self.head_dim))
+        self.V_Cache = q.new_zeros((bsz, q_len + self.max_len + 128, self.num_key_value_heads, self.head_dim))
+        attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache, window_left=self.WINDOW)
+        return self.o_proj(attn.reshape(bsz, q_len, self.hidden_size))
+
+    def decoding(self, hidden_states, position_embeddings, cache_lens, K_Cache, V_Cache, llm_kv_len=None):   # :235-270
+        bsz, q_len, _ = hidden_states.size()
+        if K_Cache is None:
+            q, k, v = self._qkv(hidden_states, position_embeddings)
+            attn = self.ops.kvcache_attention(q, self.K_Cache, self.V_Cache, k, v, window_size=(self.WINDOW, -1), causal=True,
+                                              cache_seqlens=cache_lens.int(), kv_len_hint=self.kv_len_hint)
+        else:
+            q, _, _ = self._qkv(hidden_states, position_embeddings, need_kv=False)
+            attn = self.ops.kvcache_attention(q, K_Cache, V_Cache, causal=True, cache_seqlens=llm_kv_len.int(),
+                                              kv_len_hint=self.llm_kv_len_hint)
+        return self.o_proj(attn.view(bsz, q_len, self.hidden_size))
+
+    def tree_decoding(self, hidden_states, position_embeddings, cache_lens, K_Cache, V_Cache, llm_kv_len=None,
+                      tree_mask=None, tree_mask_bits=None):                     # :272-329
+        bsz, q_len, _ = hidden_states.size()
+        if K_Cache is not None:
+            q, _, _ = self._qkv(hidden_states, position_embeddings, need_kv=False)
+            attn = self.ops.kvcache_attention(q, K_Cache, V_Cache, causal=False, cache_seqlens=llm_kv_len.int(),
+                                              kv_len_hint=self.llm_kv_len_hint)
+        else:
+            q, k, v = self._qkv(hidden_states, position_embeddings)
+            if tree_mask_bits is None:
+                tree_mask_bits = self.ops.pack_tree_mask(tree_mask)
+            attn = self.ops.draft_tree_attention(q, k, v, self.K_Cache, self.V_Cache, cache_lens, tree_mask_bits,
+                                                 tree_mask.size(-1), window=self.WINDOW, kv_len_hint=self.kv_len_hint)
+        return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
+
+
+class LlamaGlideDecoderLayer(nn.Module):
+    """``LlamaGlideDecoderLayer`` (``llama_glide.py:388-468``): norm -> self-attn -> +res ->
+    norm -> cross-attn -> +res -> norm -> MLP -> +res; no final norm."""
+
+    def __init__(self, config, ops=None):
+        super().__init__()
+        self.config = config
+        self.ops = ops if ops is not None else _default_ops()
+        self.hidden_size = config.hidden_size
+        self.layer_idx = 0
+        self.self_attn = GlideAttention(config, self.layer_idx, ops=self.ops)
+        self.cross_attn = GlideAttention(config, self.layer_idx, ops=self.ops)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
+        self.post_self_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
+        self.post_cross_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
+
+    def set_max_gen_len(self, max_gen_len):
+        self.self_attn.max_len = max_gen_len
+
+    def forward(self, hidden_states, position_embeddings, llm_kv, cache_lens=None, exec_type=None, llm_kv_len=None,
+                tree_mask=None):
+        bits = self.ops.pack_tree_mask(tree_mask) if tree_mask is not None else None
+        residual = hidden_states
+        hidden_states = self.input_layernorm(hidden_states)
+        hidden_states = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                       cache_lens=cache_lens, exec_type="sa_" + exec_type, tree_mask=tree_mask,
+                                       tree_mask_bits=bits)
+        hidden_states = residual + hidden_states
+        residual = hidden_states
+        hidden_states = self.post_self_attention_layernorm(hidden_states)
+        hidden_states = self.cross_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                        cache_lens=cache_lens, exec_type="ca_" + exec_type, k_cache=llm_kv[0],
+                                        v_cache=llm_kv[1], llm_kv_len=llm_kv_len, tree_mask=tree_mask, tree_mask_bits=bits)
+        hidden_states = hidden_states + residual
+        residual = hidden_states
+        hidden_states = self.post_cross_attention_layernorm(hidden_states)
+        hidden_states = self.mlp(hidden_states)
+        hidden_states = hidden_states + residual
+        return hidden_states
+
+
+def _sync(t: torch.Tensor):
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
+class LlamaGlide(LlamaForCausalLM):
+    """``LlamaGlide`` (``llama_glide.py:471-1245``).  ``LlamaGlide(config, target_model_path,
+    glide_path=None)`` loads a HF target directory and the draft checkpoint directory
+    (safetensors / .bin) when paths are given; ``target_model_path=None`` builds random-init
+    modules (tests, synthetic benchmarks)."""
+
+    def __init__(self, config, target_model_path=None, glide_path=None, ops=None, dtype=torch.float16, device=None):
+        super().__init__(config, ops=ops)
+        self.glide = LlamaGlideDecoderLayer(config, ops=self.ops)
+        if target_model_path is not None or glide_path is not None:
+            from .checkpoint import load_draft_checkpoint, load_target_checkpoint
+            if target_model_path is not None:
+                load_target_checkpoint(self, target_model_path)
+            if glide_path is not None:
+                load_draft_checkpoint(self.glide, glide_path)
+        self.to(dtype)
+        if device is not None:
+            self.to(device)
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+
+    # ------------------------------------------------------------------------------------------
+    def set_max_gen_len(self, max_gen_len):
+        super().set_max_gen_len(max_gen_len)
+
+    def _set_hints(self, target_bound: Optional[int], draft_bound: Optional[int]):
+        """Host-side upper bounds of the KV lengths the next kernels will see."""
+        self.model.set_kv_len_hint(target_bound)
+        self.glide.self_attn.kv_len_hint = draft_bound
+        self.glide.cross_attn.llm_kv_len_hint = target_bound
+
+    def _last_kv(self):
+        attn = self.model.layers[-1].self_attn
+        return attn.K_Cache, attn.V_Cache
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def vanilla_generate(self, input_ids, prompt_length, max_gen_len=64, eos_id=151645):       # :552-585
+        assert input_ids is not None, "please give the input"
+        bsz = input_ids.size(0)
+        output_ids = input_ids.new_zeros((bsz, max_gen_len))
+        self.set_max_gen_len(max_gen_len)
+        cache_lens = input_ids.new_zeros((bsz)).int()
+        P = int(input_ids.size(1))
+        self._set_hints(P, P)
+        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+        input_len = prompt_length
+        rows = torch.arange(bsz, device=input_ids.device)
+        output_ids[:, 0] = self.lm_head(hidden_states[rows, input_len - 1, :]).argmax(dim=-1)
+        cache_lens += input_len.int()
+        num = 0
+        eos = getattr(self.config, "eos_token_id", None)
+        _sync(input_ids)
+        start_time = time.time()
+        for step in range(1, max_gen_len):
+            self._set_hints(P + step, P + step)
+            cur = output_ids[rows, (cache_lens - input_len).long()].view(bsz, -1)
+            hidden_states = self.model.forward(cur, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
+            llm_output = self.lm_head(hidden_states[:, -1, :]).argmax(dim=-1)
+            cache_lens += 1
+            num += bsz
+            output_ids[rows, (cache_lens - input_len).long()] = llm_output.view(-1)
+            if eos is not None and (step % 16 == 0 or step == max_gen_len - 1):
+                if bool((output_ids[:, :step + 1].eq(eos)).any()):
+                    break
+        _sync(input_ids)
+        elapsed_time = time.time() - start_time
+        if eos is not None:
+            output_ids, num = _truncate_after_eos_vanilla(output_ids, num, eos, bsz)
+        return output_ids, num, elapsed_time
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def spec_generate(self, input_ids, prompt_length, gamma=4, max_gen_len=64, eos_id=151645, temperature=0.0):   # :621-774
+        assert input_ids is not None, "please give the input"
+        if temperature > 0:
+            raise NotImplementedError("temperature > 0 is a 'next' row (SURVEY 8(f).4)")
+        bsz = input_ids.size(0)
+        assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
+        dev = input_ids.device
+        output_ids = input_ids.new_zeros((bsz, max_gen_len + gamma))
+        spec_mask = input_ids.new_zeros((bsz, max_gen_len + gamma))
+        self.set_max_gen_len(max_gen_len + 128)
+        self.glide.set_max_gen_len(max_gen_len + 128)
+        P = int(input_ids.size(1))
+        self._set_hints(P, P)
+        cache_lens = input_ids.new_zeros((bsz)).int()
+        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+        input_len = prompt_length
+        rows = torch.arange(bsz, device=dev)
+        logits = self.lm_head(hidden_states[rows, input_len - 1, :])
+        output_ids[:, 0] = logits.argmax(dim=-1)
+        cache_lens += input_len.int()
+        draft_cache_lens = cache_lens.clone()
+        spec_buffer = output_ids.new_zeros((bsz, gamma + 1))
+        spec_buffer[:, 0] = output_ids[:, 0]
+        # glide prefill
+        hidden_states = self.model.embed_tokens(input_ids)
+        position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
+        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
+                   cache_lens=draft_cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
+        double_flag = False
+        double_input = None
+        next_spec_start_token = output_ids.new_zeros((bsz, 2))
+        count = 0
+        num = 0
+        next_spec_start_token[:, 0] = output_ids[:, 0]
+        emitted = 1                      # host mirror of cache_lens - input_len + 1
+        eos = getattr(self.config, "eos_token_id", None)
+        _sync(input_ids)
+        start_time = time.time()
+        for out_index in range(1, max_gen_len):
+            bound = P + emitted + gamma + 2
+            self._set_hints(bound, bound)
+            for spec_steps in range(0, gamma):
+                if spec_steps == 0:
+                    if double_flag:
+                        hidden_states = self.model.embed_tokens(next_spec_start_token[:, 0:2])
+                        position_ids = torch.arange(0, 2, device=dev)[None, :] + draft_cache_lens[:, None]
+                    else:
+                        hidden_states = self.model.embed_tokens(next_spec_start_token[:, 0, None])
+                        position_ids = draft_cache_lens[:, None]
+                else:
+                    hidden_states = self.model.embed_tokens(spec_buffer[:, spec_steps, None])
+                    position_ids = draft_cache_lens[:, None]
+                position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+                hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
+                                           llm_kv_len=cache_lens.clone(), exec_type="decoding")
+                if double_flag and spec_steps == 0:
+                    draft_cache_lens += 1 + double_input
+                    current_logp = self.lm_head(hidden_states[:, -2:, :])
+                    spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1)[rows, double_input.long()]
+                else:
+                    draft_cache_lens += 1
+                    current_logp = self.lm_head(hidden_states[:, -1, :])
+                    spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1).view(-1,)
+            hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
+            llm_verify_output = self.lm_head(hidden_states[:, -gamma - 1:, :]).argmax(dim=-1)
+            verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
+            correct_len = verification.sum(dim=-1) + 1
+            llm_verify_output[:, 1:] = llm_verify_output[:, 1:] * verification
+            col = (cache_lens - input_len).long().unsqueeze(1) + torch.arange(1, gamma + 1, device=dev)
+            output_ids[rows.unsqueeze(1), col] = llm_verify_output[:, :gamma]
+            bonus_token = llm_verify_output[rows, correct_len - 1]
+            output_ids[rows, (cache_lens - input_len).long() + correct_len] = bonus_token
+            cache_lens += correct_len.int()
+            double_input = correct_len.eq(gamma + 1).to(torch.int)
+            n_ok = int(correct_len[0])                       # the one host read of this round
+            double_flag = n_ok == gamma + 1
+            if double_flag:
+                next_spec_start_token[:, 0] = llm_verify_output[rows, correct_len - 2]
+                next_spec_start_token[:, 1] = llm_verify_output[rows, correct_len - 1]
+                next_spec_start_token[:, 0] = (1 - double_input) * next_spec_start_token[:, 1] + double_input * next_spec_start_token[:, 0]
+            else:
+                next_spec_start_token[:, 0] = bonus_token
+            spec_buffer[:, 0] = bonus_token
+            count += n_ok - 1
+            num += bsz
+            emitted += n_ok
+            draft_cache_lens = cache_lens - double_input
+            if emitted - 1 + gamma + 2 > output_ids.size(1):
+                break
+            if eos is not None and bool((output_ids[:, :emitted + 1].eq(eos)).any()):
+                break
+        _sync(input_ids)
+        elapsed_time = time.time() - start_time
+        return output_ids, count, num, elapsed_time, spec_mask
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def tree_spec_generate(self, input_ids, prompt_length, tree_shape: Optional[List[int]] = None, max_gen_len=64,
+                           eos_id=151645, temperature=0.0):                                   # :915-1126
+        assert input_ids is not None, "please give the input"
+        if temperature > 0:
+            raise NotImplementedError("temperature > 0 (verify_stochastic) is a 'next' row (SURVEY 8(f).4)")
+        bsz = input_ids.size(0)
+        assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
+        dev = input_ids.device
+        self.set_max_gen_len(max_gen_len + 256)
+        self.glide.set_max_gen_len(max_gen_len + 256)
+        cand = [4, 16, 16, 16, 16] if tree_shape is None else list(tree_shape)
+        acc_n = [1]
+        for c in cand:
+            acc_n.append(acc_n[-1] + c)
+        Fn = acc_n[-1]                       # tree nodes incl. the root
+        gamma = len(cand)
+        R = Fn - 1 + gamma + 1               # verification rows: [a accepted | F-1 tree | pads]
+        output_ids = input_ids.new_zeros((bsz, max_gen_len)).fill_(eos_id)
+        spec_mask = input_ids.new_zeros((bsz, max_gen_len))
+        input_len = prompt_length
+        P = int(input_ids.size(1))
+        cache_lens = input_ids.new_zeros((bsz)).int()
+        target_cache_lens_for_draft = input_ids.new_zeros((bsz)).int()
+        draft_cache_lens = input_ids.new_zeros((bsz)).int()
+        count = 0
+        num = 0
+        rows = torch.arange(bsz, device=dev)
+        # prefill LLM
+        self._set_hints(P, P)
+        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+        output_prob = self.lm_head(hidden_states[rows, input_len - 1, ...])
+        output_ids[:, 0] = output_prob.argmax(dim=-1)
+        num += bsz
+        cache_lens += input_len.int()
+        target_cache_lens_for_draft += input_len.int()
+        draft_cache_lens += input_len.int()
+        vocab_size = output_prob.size(-1)
+        all_spec = output_ids.new_zeros((bsz, Fn))
+        all_spec[:, 0] = output_ids[:, 0]
+        # prefill glide
+        position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
+        hidden_states = self.model.embed_tokens(input_ids)
+        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
+                   cache_lens=draft_cache_lens.clone(), llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="prefill")
+        acc_ids = output_ids[:, 0].unsqueeze(-1)
+        a = 1                                 # host mirror of acc_num (G9: pad id is outside the vocab)
+        emitted = 1                           # tokens written to output_ids so far
+        tree_mask = input_ids.new_zeros(bsz, Fn, Fn)
+        tree_mask[:, :, 0] = 1
+        diag_one = torch.eye(Fn, dtype=tree_mask.dtype, device=dev)[None].expand(bsz, -1, -1)
+        history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
+        tril = torch.tril(torch.ones((R, R), dtype=tree_mask.dtype, device=dev))
+        eos = getattr(self.config, "eos_token_id", None)
+        last_attn = self.model.layers[-1].self_attn
+        _sync(input_ids)
+        start_time = time.time()
+        for out_index in range(1, max_gen_len):
+            history_logp_sum.zero_()
+            # host bounds: target/draft caches hold < P + emitted + R rows this round
+            self._set_hints(P + emitted + R, P + emitted + Fn)
+            # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
+            hidden_states = self.model.embed_tokens(acc_ids)
+            position_ids = torch.arange(0, a, device=dev)[None, :] + draft_cache_lens[:, None]
+            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                       llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
+                                       llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="decoding")
+            draft_cache_lens += a - 1
+            current_logp = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, -1).float().log_softmax(dim=-1)
+            topk_logp, pred_ids = current_logp.topk(dim=-1, k=cand[0], largest=True, sorted=True)
+            tree_mask[:, 1:acc_n[1]] += diag_one[:, 1:acc_n[1]]
+            current_tree_mask = tree_mask[:, 1:acc_n[1], :acc_n[1]]
+            all_spec[:, 1:acc_n[1]] = pred_ids
+            history_logp_sum[:, 1:acc_n[1]] = topk_logp
+            # ---- D1..: tree levels (:1029-1075)
+            for ms in range(1, gamma):
+                pred_num = cand[ms]
+                hidden_states = self.model.embed_tokens(all_spec[:, acc_n[ms - 1]:acc_n[ms]])
+                position_ids = self.ops.tree_positions(current_tree_mask.contiguous(), draft_cache_lens)   # p + depth (:1032)
+                position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+                hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
+                                           llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="tree_decoding",
+                                           tree_mask=current_tree_mask.contiguous())
+                current_logp = self.lm_head(hidden_states).float().log_softmax(dim=-1)
+                current_logp_sum = current_logp + history_logp_sum[:, acc_n[ms - 1]:acc_n[ms], None]
+                topk_logp_sum, topk_indices = current_logp_sum.view(bsz, -1).topk(dim=-1, k=pred_num)     # beam tree (:1064)
+                father_ids = topk_indices // vocab_size + acc_n[ms - 1]
+                pred_ids = topk_indices % vocab_size
+                tree_mask[:, acc_n[ms]:acc_n[ms + 1]] = (torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn))
+                                                         + diag_one[:, acc_n[ms]:acc_n[ms + 1]])
+                current_tree_mask = tree_mask[:, acc_n[ms]:acc_n[ms + 1], :acc_n[ms + 1]]
+                all_spec[:, acc_n[ms]:acc_n[ms + 1]] = pred_ids
+                history_logp_sum[:, acc_n[ms]:acc_n[ms + 1]] = topk_logp_sum
+            draft_cache_lens += 1
+            # ---- V: one R-row target pass (:1078-1091)
+            veri_spec = tree_mask.new_zeros((bsz, R))
+            veri_spec[:, :a] = acc_ids
+            veri_spec[:, a:a + Fn - 1] = all_spec[:, 1:]
+            new_tree_mask = tril.clone()[None].expand(bsz, -1, -1).contiguous()
+            new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
+            new_tree_mask = torch.tril(new_tree_mask)
+            hidden_states = self.model.forward(veri_spec, cache_lens=cache_lens.clone(), exec_type="tree_decoding",
+                                               tree_mask=new_tree_mask).last_hidden_state
+            hidden_states = hidden_states[:, a - 1:a + Fn - 1]
+            all_llm_pred = self.lm_head(hidden_states).argmax(dim=-1)
+            # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
+            cache_lens += a - 1
+            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
+                all_spec, all_llm_pred, tree_mask, cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
+            cache_lens += 1
+            # emitted tokens -> output_ids (device-side, fixed shape), EOS test on the whole buffer as
+            # the reference does (:1120, G8), then ONE host read for (acc_num, eos flag)
+            sl = output_ids[:, emitted:emitted + gamma + 1]
+            keep = torch.arange(gamma + 1, device=dev)[None, :] < acc_num_t[:, None]
+            sl.copy_(torch.where(keep, acc_pad, sl))
+            hit_t = output_ids.eq(eos).any().to(torch.int64) if eos is not None else acc_num_t.new_zeros(())
+            a, hit = [int(v) for v in torch.stack([acc_num_t[0], hit_t]).tolist()]
+            acc_ids = acc_pad[:, :a]
+            target_cache_lens_for_draft += a
+            emitted += a
+            count += a - 1
+            num += bsz
+            tree_mask.fill_(0)
+            tree_mask[:, :, 0] = 1
+            all_spec.fill_(0)
+            all_spec[:, 0] = acc_ids[:, a - 1]
+            if emitted + gamma + 2 > output_ids.size(1):               # :1118
+                break
+            if hit:                                                    # :1120
+                break
+        _sync(input_ids)
+        elapsed_time = time.time() - start_time
+        return output_ids, count, num, elapsed_time, spec_mask
+
+    # ------------------------------------------------------------------------------------------
+    def tree_verification(self, input_ids, output_ids, tree_mask, cache_lens, non_leaf_len):      # :1128-1175
+        """Drop-in for ``LlamaGlide.tree_verification``: returns (acc_ids [bsz, acc_max],
+        acc_num [bsz], double_input [bsz] int) and moves the last layer's KV rows."""
+        depth = int(tree_mask.sum(dim=-1).max())
+        last_attn = self.model.layers[-1].self_attn
+        acc_pad, acc_num, double_input, _ = self.ops.tree_collapse(input_ids, output_ids, tree_mask, cache_lens, non_leaf_len,
+                                                                   depth, last_attn.K_Cache, last_attn.V_Cache)
+        return acc_pad[:, :int(acc_num.max())], acc_num, double_input
+
+
+def _truncate_after_eos_vanilla(output_ids, num, eos, bsz):
+    """The reference tests for EOS after every token and stops (``llama_glide.py:578``); this
+    loop tests every 16 tokens to avoid a device sync per token, then restores the reference's
+    visible result: tokens after the first EOS are zero, ``num`` counts forward passes up to it."""
+    hit = output_ids.eq(eos)
+    if not bool(hit.any()):
+        return output_ids, num
+    first = int(hit.float().argmax(dim=-1).min())
+    output_ids[:, first + 1:] = 0
+    return output_ids, first * bsz

@@ -125,6 +125,14 @@ def build_ref_model(llama, llama_glide, cfg, tgt_sd, drf_sd):
             self.glide = llama_glide.LlamaGlideDecoderLayer(config)
 
     m = RefGlide(hc).half().eval()
+    # .half() also rounds the (buffer) inv_freq of every rotary module to fp16; the reference's real
+    # load path (from_pretrained(torch_dtype=float16)) leaves that non-persistent buffer in fp32
+    for mod in m.modules():
+        if hasattr(mod, "inv_freq") and hasattr(mod, "compute_default_rope_parameters"):
+            inv, _ = mod.compute_default_rope_parameters(hc)
+            mod.inv_freq = inv.float()
+            if hasattr(mod, "original_inv_freq"):
+                mod.original_inv_freq = inv.float().clone()
     missing, unexpected = m.load_state_dict({**tgt_sd, **{"glide." + k: v for k, v in drf_sd.items()}}, strict=False)
     assert not unexpected, unexpected
     assert all("rotary_emb" in k or "inv_freq" in k for k in missing), missing

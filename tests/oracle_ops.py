@@ -1,0 +1,70 @@
+"""The operator interface of ``longspec_amd.ops`` implemented with the CPU oracle, so that the
+host logic (model wiring, cache-length state machine, tree growth, generate loops) can be
+exercised without a GPU.  Lives under tests/: the product never imports it."""
+import torch
+
+from oracle import ref_ops
+
+
+def rmsnorm(x, weight, eps, residual=None):
+    if residual is not None:
+        s = residual + x
+        return ref_ops.rmsnorm(s, weight, eps), s
+    return ref_ops.rmsnorm(x, weight, eps)
+
+
+def rope_cos_sin(position_ids, inv_freq, attention_scaling, dtype):
+    return ref_ops.rope_cos_sin(position_ids, inv_freq, attention_scaling, dtype)
+
+
+def rope_apply_(q, k, cos, sin):
+    q.copy_(ref_ops.apply_rope(q, cos, sin))
+    if k.numel():
+        k.copy_(ref_ops.apply_rope(k, cos, sin))
+    return q, k
+
+
+def pack_tree_mask(tree_mask):
+    return tree_mask            # the oracle consumes the int mask directly
+
+
+def tree_positions(tree_mask, base):
+    pos = tree_mask.sum(dim=-1) - 1
+    return pos + base[:, None].long() if base is not None else pos
+
+
+def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, causal=False, window_size=(-1, -1),
+                      return_softmax_lse=False, softmax_scale=None, kv_len_hint=None, n_splits=0):
+    return ref_ops.kvcache_attention(q, k_cache, v_cache, k, v, cache_seqlens=cache_seqlens, causal=causal,
+                                     window_size=window_size, return_softmax_lse=return_softmax_lse,
+                                     softmax_scale=softmax_scale)
+
+
+def verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, last_layer, softmax_scale=1 / (128 ** 0.5),
+                     kv_len_hint=None, n_splits=0):
+    return ref_ops.target_verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, last_layer, softmax_scale)
+
+
+def draft_tree_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, N, window=512, kv_len_hint=None):
+    return ref_ops.draft_tree_self_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, window)
+
+
+def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache=None, v_cache=None):
+    acc_ids, acc_num, dbl, imap = ref_ops.tree_verification(all_spec, all_llm_pred, tree_mask, non_leaf_len)
+    if k_cache is not None:
+        ref_ops.move_accepted_kv(k_cache, v_cache, cache_lens, imap)
+    b, n = acc_ids.shape
+    pad_ids = torch.zeros((b, max_acc), dtype=torch.int64)
+    pad_map = torch.full((b, max_acc), -1, dtype=torch.int64)
+    for z in range(b):
+        m = int(acc_num[z])
+        pad_ids[z, :m] = acc_ids[z, :m]
+        pad_map[z, :m] = imap[z, :m]
+    return pad_ids, acc_num, dbl, pad_map
+
+
+def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1):
+    L = q.shape[1]
+    k_cache[:, :L] = k
+    v_cache[:, :L] = v
+    return ref_ops.flash_attention(q, k, v, causal=True, window_size=(window_left, -1))
