@@ -345,6 +345,38 @@ class LlamaGlide(LlamaForCausalLM):
         dev = input_ids.device
         self.set_max_gen_len(max_gen_len + 256)
         self.glide.set_max_gen_len(max_gen_len + 256)
+        P = int(input_ids.size(1))
+        input_len = prompt_length
+        rows = torch.arange(bsz, device=dev)
+        # prefill LLM (:954-960)
+        self._set_hints(P, P)
+        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+        first = self.lm_head(hidden_states[rows, input_len - 1, ...]).argmax(dim=-1)
+        # prefill glide (:968-975)
+        lens = input_len.to(device=dev, dtype=torch.int32).view(bsz)
+        position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
+        hidden_states = self.model.embed_tokens(input_ids)
+        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
+                   cache_lens=lens.clone(), llm_kv_len=lens.clone(), exec_type="prefill")
+        st = self.begin_tree_decode(first, lens, P, tree_shape, max_gen_len, eos_id)
+        _sync(input_ids)
+        start_time = time.time()
+        for out_index in range(1, max_gen_len):
+            if not self.tree_round(st):
+                break
+        _sync(input_ids)
+        elapsed_time = time.time() - start_time
+        return st.output_ids, st.count, st.num, elapsed_time, st.spec_mask
+
+    def begin_tree_decode(self, first_token, cache_lens, prompt_bound: int, tree_shape=None, max_gen_len=64, eos_id=151645):
+        """State of the round loop right after the two prefills (``llama_glide.py:927-991``).
+        ``first_token`` [bsz] = the target's first generated token, ``cache_lens`` [bsz] int32 = valid
+        rows of every KV cache, ``prompt_bound`` = host-side bound of it.  Also the entry point of
+        synthetic-KV benchmarks, which fill the caches themselves instead of prefilling."""
+        from types import SimpleNamespace
+        dev = first_token.device
+        bsz = first_token.shape[0]
         cand = [4, 16, 16, 16, 16] if tree_shape is None else list(tree_shape)
         acc_n = [1]
         for c in cand:
@@ -352,124 +384,114 @@ class LlamaGlide(LlamaForCausalLM):
         Fn = acc_n[-1]                       # tree nodes incl. the root
         gamma = len(cand)
         R = Fn - 1 + gamma + 1               # verification rows: [a accepted | F-1 tree | pads]
-        output_ids = input_ids.new_zeros((bsz, max_gen_len)).fill_(eos_id)
-        spec_mask = input_ids.new_zeros((bsz, max_gen_len))
-        input_len = prompt_length
-        P = int(input_ids.size(1))
-        cache_lens = input_ids.new_zeros((bsz)).int()
-        target_cache_lens_for_draft = input_ids.new_zeros((bsz)).int()
-        draft_cache_lens = input_ids.new_zeros((bsz)).int()
-        count = 0
-        num = 0
-        rows = torch.arange(bsz, device=dev)
-        # prefill LLM
-        self._set_hints(P, P)
-        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
-        output_prob = self.lm_head(hidden_states[rows, input_len - 1, ...])
-        output_ids[:, 0] = output_prob.argmax(dim=-1)
-        num += bsz
-        cache_lens += input_len.int()
-        target_cache_lens_for_draft += input_len.int()
-        draft_cache_lens += input_len.int()
-        vocab_size = output_prob.size(-1)
-        all_spec = output_ids.new_zeros((bsz, Fn))
-        all_spec[:, 0] = output_ids[:, 0]
-        # prefill glide
-        position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
-        hidden_states = self.model.embed_tokens(input_ids)
-        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
-                   cache_lens=draft_cache_lens.clone(), llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="prefill")
-        acc_ids = output_ids[:, 0].unsqueeze(-1)
-        a = 1                                 # host mirror of acc_num (G9: pad id is outside the vocab)
-        emitted = 1                           # tokens written to output_ids so far
-        tree_mask = input_ids.new_zeros(bsz, Fn, Fn)
-        tree_mask[:, :, 0] = 1
-        diag_one = torch.eye(Fn, dtype=tree_mask.dtype, device=dev)[None].expand(bsz, -1, -1)
-        history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
-        tril = torch.tril(torch.ones((R, R), dtype=tree_mask.dtype, device=dev))
-        eos = getattr(self.config, "eos_token_id", None)
+        st = SimpleNamespace(cand=cand, acc_n=acc_n, Fn=Fn, gamma=gamma, R=R, P=prompt_bound, dev=dev, bsz=bsz)
+        st.output_ids = torch.full((bsz, max_gen_len), eos_id, dtype=torch.int64, device=dev)       # :937 (G8)
+        st.spec_mask = torch.zeros((bsz, max_gen_len), dtype=torch.int64, device=dev)
+        st.output_ids[:, 0] = first_token
+        st.cache_lens = cache_lens.clone()
+        st.target_cache_lens_for_draft = cache_lens.clone()
+        st.draft_cache_lens = cache_lens.clone()
+        st.count, st.num = 0, bsz
+        st.all_spec = torch.zeros((bsz, Fn), dtype=torch.int64, device=dev)
+        st.all_spec[:, 0] = first_token
+        st.acc_ids = first_token.view(bsz, 1).clone()
+        st.a = 1                              # host mirror of acc_num (G9: the pad id is outside the vocab)
+        st.emitted = 1                        # tokens written to output_ids so far
+        st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
+        st.tree_mask[:, :, 0] = 1
+        st.diag_one = torch.eye(Fn, dtype=torch.int64, device=dev)[None].expand(bsz, -1, -1)
+        st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
+        st.tril = torch.tril(torch.ones((R, R), dtype=torch.int64, device=dev))
+        st.eos = getattr(self.config, "eos_token_id", None)
+        st.arange_g = torch.arange(gamma + 1, device=dev)[None, :]
+        return st
+
+    def tree_round(self, st) -> bool:
+        """One draft-then-verify round (``llama_glide.py:997-1121``): 1 + (gamma-1) draft passes growing
+        the beam tree, one R-row target pass, accept/collapse.  Returns False when generation must stop."""
+        cand, acc_n, Fn, gamma, R, dev, bsz = st.cand, st.acc_n, st.Fn, st.gamma, st.R, st.dev, st.bsz
+        tree_mask, all_spec, diag_one, history_logp_sum = st.tree_mask, st.all_spec, st.diag_one, st.history_logp_sum
+        a = st.a
         last_attn = self.model.layers[-1].self_attn
-        _sync(input_ids)
-        start_time = time.time()
-        for out_index in range(1, max_gen_len):
-            history_logp_sum.zero_()
-            # host bounds: target/draft caches hold < P + emitted + R rows this round
-            self._set_hints(P + emitted + R, P + emitted + Fn)
-            # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
-            hidden_states = self.model.embed_tokens(acc_ids)
-            position_ids = torch.arange(0, a, device=dev)[None, :] + draft_cache_lens[:, None]
+        history_logp_sum.zero_()
+        # host bounds: no cache holds more than P + emitted (+ this round's speculative rows) valid rows
+        self._set_hints(st.P + st.emitted + R, st.P + st.emitted + Fn)
+        # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
+        hidden_states = self.model.embed_tokens(st.acc_ids)
+        position_ids = torch.arange(0, a, device=dev)[None, :] + st.draft_cache_lens[:, None]
+        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+        hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                   llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
+                                   llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="decoding")
+        st.draft_cache_lens += a - 1
+        current_logp = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, -1).float().log_softmax(dim=-1)
+        vocab_size = current_logp.size(-1)
+        topk_logp, pred_ids = current_logp.topk(dim=-1, k=cand[0], largest=True, sorted=True)
+        tree_mask[:, 1:acc_n[1]] += diag_one[:, 1:acc_n[1]]
+        current_tree_mask = tree_mask[:, 1:acc_n[1], :acc_n[1]]
+        all_spec[:, 1:acc_n[1]] = pred_ids
+        history_logp_sum[:, 1:acc_n[1]] = topk_logp
+        # ---- D1..: tree levels (:1029-1075)
+        for ms in range(1, gamma):
+            pred_num = cand[ms]
+            hidden_states = self.model.embed_tokens(all_spec[:, acc_n[ms - 1]:acc_n[ms]])
+            ctm = current_tree_mask.contiguous()
+            position_ids = self.ops.tree_positions(ctm, st.draft_cache_lens)                              # p + depth (:1032)
             position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
             hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                       llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
-                                       llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="decoding")
-            draft_cache_lens += a - 1
-            current_logp = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, -1).float().log_softmax(dim=-1)
-            topk_logp, pred_ids = current_logp.topk(dim=-1, k=cand[0], largest=True, sorted=True)
-            tree_mask[:, 1:acc_n[1]] += diag_one[:, 1:acc_n[1]]
-            current_tree_mask = tree_mask[:, 1:acc_n[1], :acc_n[1]]
-            all_spec[:, 1:acc_n[1]] = pred_ids
-            history_logp_sum[:, 1:acc_n[1]] = topk_logp
-            # ---- D1..: tree levels (:1029-1075)
-            for ms in range(1, gamma):
-                pred_num = cand[ms]
-                hidden_states = self.model.embed_tokens(all_spec[:, acc_n[ms - 1]:acc_n[ms]])
-                position_ids = self.ops.tree_positions(current_tree_mask.contiguous(), draft_cache_lens)   # p + depth (:1032)
-                position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-                hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
-                                           llm_kv_len=target_cache_lens_for_draft.clone(), exec_type="tree_decoding",
-                                           tree_mask=current_tree_mask.contiguous())
-                current_logp = self.lm_head(hidden_states).float().log_softmax(dim=-1)
-                current_logp_sum = current_logp + history_logp_sum[:, acc_n[ms - 1]:acc_n[ms], None]
-                topk_logp_sum, topk_indices = current_logp_sum.view(bsz, -1).topk(dim=-1, k=pred_num)     # beam tree (:1064)
-                father_ids = topk_indices // vocab_size + acc_n[ms - 1]
-                pred_ids = topk_indices % vocab_size
-                tree_mask[:, acc_n[ms]:acc_n[ms + 1]] = (torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn))
-                                                         + diag_one[:, acc_n[ms]:acc_n[ms + 1]])
-                current_tree_mask = tree_mask[:, acc_n[ms]:acc_n[ms + 1], :acc_n[ms + 1]]
-                all_spec[:, acc_n[ms]:acc_n[ms + 1]] = pred_ids
-                history_logp_sum[:, acc_n[ms]:acc_n[ms + 1]] = topk_logp_sum
-            draft_cache_lens += 1
-            # ---- V: one R-row target pass (:1078-1091)
-            veri_spec = tree_mask.new_zeros((bsz, R))
-            veri_spec[:, :a] = acc_ids
-            veri_spec[:, a:a + Fn - 1] = all_spec[:, 1:]
-            new_tree_mask = tril.clone()[None].expand(bsz, -1, -1).contiguous()
-            new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
-            new_tree_mask = torch.tril(new_tree_mask)
-            hidden_states = self.model.forward(veri_spec, cache_lens=cache_lens.clone(), exec_type="tree_decoding",
-                                               tree_mask=new_tree_mask).last_hidden_state
-            hidden_states = hidden_states[:, a - 1:a + Fn - 1]
-            all_llm_pred = self.lm_head(hidden_states).argmax(dim=-1)
-            # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
-            cache_lens += a - 1
-            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
-                all_spec, all_llm_pred, tree_mask, cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
-            cache_lens += 1
-            # emitted tokens -> output_ids (device-side, fixed shape), EOS test on the whole buffer as
-            # the reference does (:1120, G8), then ONE host read for (acc_num, eos flag)
-            sl = output_ids[:, emitted:emitted + gamma + 1]
-            keep = torch.arange(gamma + 1, device=dev)[None, :] < acc_num_t[:, None]
-            sl.copy_(torch.where(keep, acc_pad, sl))
-            hit_t = output_ids.eq(eos).any().to(torch.int64) if eos is not None else acc_num_t.new_zeros(())
-            a, hit = [int(v) for v in torch.stack([acc_num_t[0], hit_t]).tolist()]
-            acc_ids = acc_pad[:, :a]
-            target_cache_lens_for_draft += a
-            emitted += a
-            count += a - 1
-            num += bsz
-            tree_mask.fill_(0)
-            tree_mask[:, :, 0] = 1
-            all_spec.fill_(0)
-            all_spec[:, 0] = acc_ids[:, a - 1]
-            if emitted + gamma + 2 > output_ids.size(1):               # :1118
-                break
-            if hit:                                                    # :1120
-                break
-        _sync(input_ids)
-        elapsed_time = time.time() - start_time
-        return output_ids, count, num, elapsed_time, spec_mask
+                                       llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
+                                       llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="tree_decoding",
+                                       tree_mask=ctm)
+            current_logp = self.lm_head(hidden_states).float().log_softmax(dim=-1)
+            current_logp_sum = current_logp + history_logp_sum[:, acc_n[ms - 1]:acc_n[ms], None]
+            topk_logp_sum, topk_indices = current_logp_sum.view(bsz, -1).topk(dim=-1, k=pred_num)         # beam tree (:1064)
+            father_ids = topk_indices // vocab_size + acc_n[ms - 1]
+            pred_ids = topk_indices % vocab_size
+            tree_mask[:, acc_n[ms]:acc_n[ms + 1]] = (torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn))
+                                                     + diag_one[:, acc_n[ms]:acc_n[ms + 1]])
+            current_tree_mask = tree_mask[:, acc_n[ms]:acc_n[ms + 1], :acc_n[ms + 1]]
+            all_spec[:, acc_n[ms]:acc_n[ms + 1]] = pred_ids
+            history_logp_sum[:, acc_n[ms]:acc_n[ms + 1]] = topk_logp_sum
+        st.draft_cache_lens += 1
+        # ---- V: one R-row target pass (:1078-1091)
+        veri_spec = tree_mask.new_zeros((bsz, R))
+        veri_spec[:, :a] = st.acc_ids
+        veri_spec[:, a:a + Fn - 1] = all_spec[:, 1:]
+        new_tree_mask = st.tril.clone()[None].expand(bsz, -1, -1).contiguous()
+        new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
+        new_tree_mask = torch.tril(new_tree_mask)
+        hidden_states = self.model.forward(veri_spec, cache_lens=st.cache_lens.clone(), exec_type="tree_decoding",
+                                           tree_mask=new_tree_mask).last_hidden_state
+        hidden_states = hidden_states[:, a - 1:a + Fn - 1]
+        all_llm_pred = self.lm_head(hidden_states).argmax(dim=-1)
+        # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
+        st.cache_lens += a - 1
+        acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
+            all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
+        st.cache_lens += 1
+        # emitted tokens -> output_ids (device-side, fixed shape), EOS test on the whole buffer as the
+        # reference does (:1120, G8), then ONE host read for (acc_num, eos flag)
+        emitted = st.emitted
+        sl = st.output_ids[:, emitted:emitted + gamma + 1]
+        keep = st.arange_g < acc_num_t[:, None]
+        sl.copy_(torch.where(keep, acc_pad, sl))
+        hit_t = st.output_ids.eq(st.eos).any().to(torch.int64) if st.eos is not None else acc_num_t.new_zeros(())
+        a, hit = [int(v) for v in torch.stack([acc_num_t[0], hit_t]).tolist()]
+        st.acc_ids = acc_pad[:, :a]
+        st.a = a
+        st.target_cache_lens_for_draft += a
+        st.emitted += a
+        st.count += a - 1
+        st.num += bsz
+        tree_mask.fill_(0)
+        tree_mask[:, :, 0] = 1
+        all_spec.fill_(0)
+        all_spec[:, 0] = st.acc_ids[:, a - 1]
+        if st.emitted + gamma + 2 > st.output_ids.size(1):            # :1118
+            return False
+        if hit:                                                       # :1120
+            return False
+        return True
 
     # ------------------------------------------------------------------------------------------
     def tree_verification(self, input_ids, output_ids, tree_mask, cache_lens, non_leaf_len):      # :1128-1175

@@ -1,0 +1,43 @@
+"""End-to-end decode on the GPU through the HIP kernels: LlamaGlide.{vanilla,spec,tree_spec}_generate
+on the toy models of tests/golden against the reference's golden token ids (temperature 0)."""
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+RUNS = list(cases.generate_runs())
+
+
+def build(run):
+    from longspec_amd.llama_glide import LlamaGlide
+    m = LlamaGlide(run["cfg"], device="cuda")          # default ops = the HIP operator layer
+    m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
+    return m
+
+
+def _agree(a, b):
+    """Length of the common prefix of two 1-D token tensors."""
+    n = min(a.numel(), b.numel())
+    neq = (a[:n] != b[:n]).nonzero()
+    return n if neq.numel() == 0 else int(neq[0])
+
+
+@pytest.mark.parametrize("run", RUNS, ids=lambda r: r["name"])
+def test_generate_token_ids_match_reference(run):
+    m = build(run)
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=run["max_gen_len"])
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"])
+    s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=run["max_gen_len"])
+    n_t = int(t_count) + int(t_num)
+    n_s = min(int(s_count) + int(s_num), run["max_gen_len"])
+    # losslessness on the device itself: tree and chain decoding reproduce vanilla decoding
+    assert torch.equal(t_out[0, :n_t], v_out[0, :n_t]), "tree decoding is not lossless"
+    assert torch.equal(s_out[0, :n_s], v_out[0, :n_s]), "chain decoding is not lossless"
+    # bit-exact token ids against the reference's golden run
+    assert torch.equal(v_out.cpu(), run["vanilla_out"]), f"vanilla differs from the reference at token {_agree(v_out[0].cpu(), run['vanilla_out'][0])}"
+    assert torch.equal(t_out.cpu(), run["tree_out"])
+    assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
+    assert (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
