@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- accepted tokens/s of the LongSpec draft-then-verify decode round on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one decode round of ``LlamaGlide.tree_spec_generate`` (tree_shape 4 16 16 16 16): five
+draft passes growing the 69-node beam tree, one 74-row target pass through all 32 layers with the
+hybrid tree-verification attention, accept/collapse.  Workload at N = 1: BASELINE.json configs[1]
+(Llama-3-8B-Instruct-262k dimensions + longspec draft layer, 16k-token synthetic prefix, fp16,
+temperature 0).  For N > 1 every GPU keeps a 16k-row shard of the prefix (weak scaling: N = 8 is the
+128k-context configs[2]); the prefix KV is sequence-sharded, partial attention outputs are merged
+with one RCCL all-gather per attention call (longspec_amd/dist.py).
+
+Synthetic data: random-init weights of the named architecture made "mixed-agreement" (o_proj and
+down_proj scaled by --agreement) so that the shared-embedding draft is accepted
+some of the time without a trained checkpoint; prefix KV ~ N(0,1) written straight into the caches
+(inputs resident in HBM when the timed region starts; prefill is outside the metric, as in the
+reference: llama_glide.py:993-994).  tau is printed next to the rate because synthetic tau is not
+the published tau.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MODELS = {
+    # gradientai/Llama-3-8B-Instruct-262k
+    "llama3-8b-262k": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                           num_key_value_heads=8, vocab_size=128256, max_position_embeddings=262144, rms_norm_eps=1e-5,
+                           rope_theta=283461213.0, pad_token_id=128001, eos_token_id=128009, bos_token_id=128000),
+    # lmsys/vicuna-7b-v1.5-16k
+    "vicuna-7b-16k": dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                          num_key_value_heads=32, vocab_size=32000, max_position_embeddings=16384, rms_norm_eps=1e-5,
+                          rope_theta=10000.0, rope_scaling={"type": "linear", "factor": 4.0}, pad_token_id=0,
+                          eos_token_id=2, bos_token_id=1),
+}
+TREE = [4, 16, 16, 16, 16]
+
+
+def make_config(name):
+    d = dict(MODELS[name])
+    d.setdefault("rope_scaling", None)
+    d["head_dim"] = d["hidden_size"] // d["num_attention_heads"]
+    d.update(attention_bias=False, mlp_bias=False)
+    return SimpleNamespace(**d)
+
+
+def algo_bytes_verify(L, H, Hkv, R=74, D=128):
+    """Algorithmic bytes of one verification-attention call: K and V of the prefix, the R
+    new K/V rows, q in + o out, the mask bits."""
+    return 2 * L * Hkv * D * 2 + 2 * R * Hkv * D * 2 + 2 * R * H * D * 2 + R * R // 8
+
+
+def build_model(cfg, device, agreement, seed):
+    from longspec_amd.llama_glide import LlamaGlide
+    torch.manual_seed(seed)
+    with torch.device(device):
+        m = LlamaGlide(cfg, dtype=torch.float16)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("norm.weight"):
+                p.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.zero_()
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+                if name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+                    p.mul_(agreement)
+    return m
+
+
+def synth_kv(m, L_local, L_total, max_rows, device, seed):
+    """Prefix KV ~ N(0,1) fp16 in every target layer (local shard) and in the draft's own cache."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    cfg = m.config
+    Hkv, D = cfg.num_key_value_heads, 128
+    for layer in m.model.layers:
+        attn = layer.self_attn
+        for nm in ("K_Cache", "V_Cache"):
+            t = torch.zeros((1, L_local + max_rows, Hkv, D), dtype=torch.float16, device=device)
+            t[:, :L_local].normal_(0.0, 1.0, generator=g)
+            setattr(attn, nm, t)
+    sa = m.glide.self_attn
+    # the draft only ever reads its last 512 + tree rows; positions are absolute, so the cache is
+    # allocated like the reference's (q_len + max_len + 128 rows, llama_glide.py:223-224)
+    for nm in ("K_Cache", "V_Cache"):
+        t = torch.zeros((1, L_total + max_rows + 128, Hkv, D), dtype=torch.float16, device=device)
+        t[:, max(0, L_total - 1024):L_total].normal_(0.0, 1.0, generator=g)
+        setattr(sa, nm, t)
+
+
+class EventPool:
+    """hipEvent pairs recorded by the C ABI around the streaming kernel of every verification-attention
+    call of the timed region (on the launch stream)."""
+
+    def __init__(self, n):
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in self.ev:          # force creation of the underlying hipEvents
+            a.record()
+            b.record()
+        self.i = 0
+        self.on = False
+
+    def next(self):
+        if not self.on or self.i >= len(self.ev):
+            return None
+        p = self.ev[self.i]
+        self.i += 1
+        return p
+
+    def mean_us(self):
+        if self.i == 0:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.ev[:self.i]) * 1e3 / self.i
+
+
+def cpu_baseline(cfg, L, sample_calls, tau):
+    """The oracle's C restatement of the verification attention (kind "port"), timed on the host cores on
+    a bounded sample: `sample_calls` layer-calls at the full prefix length; a round needs one per target
+    layer (+5 draft cross-attention reads, not timed).  Expressed in the metric's unit as the token rate
+    the CPU port would reach if the round consisted of its verification attention alone."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import toy
+    from oracle import c_port
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 1235)
+    g = torch.Generator().manual_seed(1235)
+    kc = torch.randn(1, L + 80, Hkv, 128, generator=g).to(torch.float16)
+    vc = torch.randn(1, L + 80, Hkv, 128, generator=g).to(torch.float16)
+    c_port.verify_attention(q, k, v, kc, vc, 64, tm, False)             # warm-up (loads the library)
+    t0 = time.time()
+    for _ in range(sample_calls):
+        c_port.verify_attention(q, k, v, kc, vc, L, tm, False)
+    per_call = (time.time() - t0) / sample_calls
+    round_s = per_call * cfg.num_hidden_layers
+    return {"value": round(tau / round_s, 4), "unit": "accepted tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{sample_calls} calls of oracle/oracle_c.c::oracle_verify_attention_f16 (OpenMP, all host cores) at "
+                      f"L={L}, H={H}, Hkv={Hkv}, 74 rows: {per_call * 1e3:.1f} ms per layer-call; x{cfg.num_hidden_layers} "
+                      f"layers = one round's verification attention only (GEMMs and draft passes not included), at the "
+                      f"measured tau"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="llama3-8b-262k", choices=sorted(MODELS))
+    ap.add_argument("--prefix-per-gpu", type=int, default=16384)
+    ap.add_argument("--agreement", type=float, default=0.05)
+    ap.add_argument("--vanilla-steps", type=int, default=16)
+    ap.add_argument("--cpu-sample-calls", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = make_config(args.model)
+    H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    Ls = args.prefix_per_gpu
+    L_total = Ls * world
+    rounds = args.steps + args.warmup
+    max_gen = 6 * (rounds + 2) + 16
+    max_rows = max_gen + 256
+    m = build_model(cfg, device, args.agreement, seed=1234)          # replicated weights: same seed on every rank
+    m.set_max_gen_len(max_rows)
+    m.glide.set_max_gen_len(max_rows)
+    synth_kv(m, Ls, L_total, max_rows, device, seed=4321 + rank)
+    if world > 1:
+        from longspec_amd.dist import KVShard
+        shard = KVShard(rank, world, shard_rows=Ls)
+        for layer in m.model.layers:
+            layer.self_attn.shard = shard
+        m.glide.cross_attn.shard = shard
+
+    lens = torch.tensor([L_total], dtype=torch.int32, device=device)
+    first = torch.tensor([1000], dtype=torch.int64, device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pool = EventPool(cfg.num_hidden_layers * args.steps) if world == 1 else None
+    if pool is not None:
+        for layer in m.model.layers:
+            layer.self_attn.timing = pool.next
+
+    with torch.inference_mode():
+        st = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
+        st.eos = None                                    # run a fixed number of rounds
+        for _ in range(args.warmup):
+            m.tree_round(st)
+        barrier()
+        tok0 = st.emitted
+        if pool is not None:
+            pool.on = True
+        t0 = time.time()
+        for _ in range(args.steps):
+            m.tree_round(st)
+        barrier()
+        elapsed = time.time() - t0
+        if pool is not None:
+            pool.on = False
+        tokens = st.emitted - tok0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    tau = tokens / args.steps
+    value = tokens / elapsed
+
+    out = {
+        "metric": "accepted tokens/sec (tree speculative decode, temperature 0)", "value": round(value, 3),
+        "unit": "accepted tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix "
+                               f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1",
+                   "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
+                   "parallelism": "1 GPU" if world == 1 else f"prefix KV sequence-sharded x{world}, weights replicated"},
+        "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
+    }
+
+    if rank == 0 and world == 1:
+        # ---- speed-up denominator: vanilla autoregressive decode on the same model and prefix ----------
+        with torch.inference_mode():
+            cl = lens.clone()
+            tokv = first.view(1, 1).clone()
+            for layer in m.model.layers:
+                layer.self_attn.timing = None
+            m._set_hints(L_total + args.vanilla_steps + 8, L_total + 8)
+            for i in range(args.vanilla_steps + 2):
+                if i == 2:
+                    torch.cuda.synchronize()
+                    tv = time.time()
+                hs = m.model.forward(tokv, cache_lens=cl.clone(), exec_type="decoding").last_hidden_state
+                tokv = m.lm_head(hs[:, -1, :]).argmax(dim=-1).view(1, 1)
+                cl += 1
+            torch.cuda.synchronize()
+            vanilla_tps = args.vanilla_steps / (time.time() - tv)
+        out["vanilla_tokens_per_s"] = round(vanilla_tps, 3)
+        out["speedup_vs_vanilla"] = round(value / vanilla_tps, 3)
+        # ---- roofline of the dominant kernel (hybrid verification attention, stage 1) ----------------
+        mean_us = pool.mean_us()
+        ab = algo_bytes_verify(Ls, H, Hkv)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = ab / (mean_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                           "kernel": "attn_partial_kernel (verification attention, stage 1)",
+                           "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
+                           "launches_timed": pool.i,
+                           "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, Ls, args.cpu_sample_calls, tau)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

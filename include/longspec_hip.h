@@ -53,6 +53,8 @@ typedef struct ls_attn_desc {
     const uint32_t* mask_bits;    /* [b, sq, mask_words] bit j of row r = new-block key j visible */
     void* out;          /* [b, sq, H, 128] dtype                out_stride_{b,s,h}                */
     float* lse;         /* [b, H, sq] fp32 or NULL (LS_NEW_NONE / LS_NEW_FLASH only)              */
+    void* ev_start;     /* optional hipEvent_t pair recorded on `stream` around the stage-1 kernel  */
+    void* ev_stop;      /* (profiling: per-launch duration of the streaming kernel), or NULL        */
     /* dims */
     int32_t b, sq, H, Hkv;
     int32_t dtype;         /* LS_F16 / LS_BF16                                                    */
@@ -109,6 +111,7 @@ int ls_attn_reduce_local(const ls_attn_desc* d, void* workspace, size_t workspac
  * taken from `workspace` (written by ls_attn_partial).  N-way generalisation of
  * llama.py:385-387,420. */
 int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts,
+                   int64_t part_o_stride, int64_t part_lse_stride, /* elements between parts; 0 = dense */
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* N-way log-sum-exp merge of normalised partials (no new block): out [b,sq,H,128] dtype

@@ -21,6 +21,7 @@ class AttnDesc(C.Structure):
         ("q", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p),
         ("k_new", C.c_void_p), ("v_new", C.c_void_p), ("cache_seqlens", C.c_void_p),
         ("mask_bits", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p),
+        ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
         ("b", C.c_int32), ("sq", C.c_int32), ("H", C.c_int32), ("Hkv", C.c_int32),
         ("dtype", C.c_int32), ("new_mode", C.c_int32), ("n_new", C.c_int32), ("n_new_cached", C.c_int32),
         ("mask_words", C.c_int32), ("scatter_new", C.c_int32), ("causal", C.c_int32), ("window_left", C.c_int32),
@@ -45,7 +46,7 @@ SYMBOLS = {
     "ls_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_partial": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_reduce_local": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P, _P]),
-    "ls_attn_finish": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _I, _P, C.c_size_t, _P]),
+    "ls_attn_finish": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _I, _L, _L, _P, C.c_size_t, _P]),
     "ls_lse_merge": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ls_pack_tree_mask": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "ls_rmsnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P]),

@@ -629,6 +629,7 @@ struct FinK {
     float* o32;              // fp32 [b][sq][H][D] or null
     float* lse_out;          // [b][H][sq] or null
     int n_parts, b, sq, H, mode;   // mode = LS_NEW_*
+    long part_o_stride, part_lse_stride;   // elements between consecutive parts
     long out_sb, out_ss, out_sh;
 };
 
@@ -643,8 +644,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     if (r >= p.sq) return;
     const long lse_idx = ((long)bi * p.H + h) * p.sq + r;
     const long o_idx = (((long)bi * p.sq + r) * p.H + h) * D + d;
-    const long part_lse_stride = (long)p.b * p.H * p.sq;
-    const long part_o_stride = (long)p.b * p.sq * p.H * D;
+    const long part_lse_stride = p.part_lse_stride;
+    const long part_o_stride = p.part_o_stride;
     const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
 
     float mx = -INFINITY;
@@ -895,14 +896,19 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
     k.kn_sb = d->kn_stride_b; k.kn_ss = d->kn_stride_s; k.kn_sh = d->kn_stride_h;
     dim3 grid(n_splits + k.has_new, d->Hkv * c.row_chunks, d->b);
+    if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     rc = d->dtype == LS_F16 ? dispatch_partial<ElemF16>(c, k, grid, s) : dispatch_partial<ElemBF16>(c, k, grid, s);
+    if (d->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s);
     if (out_layout) *out_layout = w;
     return rc;
 }
 
 int run_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, const float* new_o,
-               const float* new_lse, int mode, void* out, float* o32, float* lse, hipStream_t s) {
+               const float* new_lse, int mode, void* out, float* o32, float* lse, hipStream_t s, long part_o_stride = 0,
+               long part_lse_stride = 0) {
     FinK f;
+    f.part_o_stride = part_o_stride ? part_o_stride : (long)d->b * d->sq * d->H * D;
+    f.part_lse_stride = part_lse_stride ? part_lse_stride : (long)d->b * d->H * d->sq;
     f.parts_o = parts_o;
     f.parts_lse = parts_lse;
     f.new_o = new_o;
@@ -969,8 +975,8 @@ int ls_attn_reduce_local(const ls_attn_desc* d, void* ws, size_t ws_bytes, float
                       w.n_parts, nullptr, nullptr, LS_NEW_NONE, nullptr, o32, lse, static_cast<hipStream_t>(stream));
 }
 
-int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, void* ws,
-                   size_t ws_bytes, void* stream) {
+int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, int64_t part_o_stride,
+                   int64_t part_lse_stride, void* ws, size_t ws_bytes, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!parts_o || !parts_lse || n_parts < 1 || !d->out) LS_FAIL(LS_ERR_INVALID_ARG, "parts/out null");
     const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
@@ -980,7 +986,7 @@ int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* par
     char* base = static_cast<char*>(ws);
     return run_finish(d, parts_o, parts_lse, n_parts, has_new ? reinterpret_cast<float*>(base + w.new_o) : nullptr,
                       has_new ? reinterpret_cast<float*>(base + w.new_lse) : nullptr, d->new_mode, d->out, nullptr,
-                      d->lse, static_cast<hipStream_t>(stream));
+                      d->lse, static_cast<hipStream_t>(stream), (long)part_o_stride, (long)part_lse_stride);
 }
 
 int ls_lse_merge(const float* parts_o, const float* parts_lse, int n_parts, int b, int sq, int H, int dtype, void* out,

@@ -117,6 +117,8 @@ class LlamaAttention(nn.Module):
         self.softmax_scale = 1 / (128 ** 0.5)          # hard-coded in the reference (llama.py:95, G1)
         self.ops = ops
         self.kv_len_hint = None                          # host-side upper bound of cache_lens (grid sizing)
+        self.timing = None                               # optional callable -> (start, stop) events (bench.py)
+        self.shard = None                                # dist.KVShard when the prefix KV is sequence-sharded
 
     def _qkv(self, hidden_states, position_embeddings):
         bsz, q_len, _ = hidden_states.size()
@@ -165,9 +167,17 @@ class LlamaAttention(nn.Module):
         else:
             if tree_mask_bits is None:
                 tree_mask_bits = self.ops.pack_tree_mask(tree_mask)
+            if self.shard is not None:
+                sh = self.shard
+                call = self.ops.sharded_verify_attention(q, k, v, self.K_Cache, self.V_Cache, sh.local_len(cache_lens),
+                                                         tree_mask_bits, self.last_layer, softmax_scale=self.softmax_scale,
+                                                         kv_len_hint=sh.local_hint(self.kv_len_hint))
+                attn = sh.attend(call)
+                return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
+            extra = {"timing": self.timing()} if self.timing is not None else {}
             attn = self.ops.verify_attention(q, k, v, self.K_Cache, self.V_Cache, cache_lens, tree_mask_bits,
                                              self.last_layer, softmax_scale=self.softmax_scale,
-                                             kv_len_hint=self.kv_len_hint)
+                                             kv_len_hint=self.kv_len_hint, **extra)
         return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
 
 

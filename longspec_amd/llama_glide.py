@@ -49,6 +49,7 @@ class GlideAttention(nn.Module):
         self.ops = ops
         self.kv_len_hint = None          # bound of the draft cache length
         self.llm_kv_len_hint = None      # bound of the target last-layer KV length
+        self.shard = None                # dist.KVShard: the target KV this layer cross-attends is sequence-sharded
 
     def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, exec_type="training",
                 k_cache=None, v_cache=None, llm_kv_len=None, tree_mask=None, tree_mask_bits=None):
@@ -79,6 +80,17 @@ class GlideAttention(nn.Module):
         self.ops.rope_apply_(q, q[:, :, :0], cos, sin)
         return q, None, None
 
+    def _cross(self, q, K_Cache, V_Cache, llm_kv_len, causal: bool):
+        """Cross-attention over the target's last-layer KV (K7), whole or sequence-sharded."""
+        if self.shard is None:
+            return self.ops.kvcache_attention(q, K_Cache, V_Cache, causal=causal, cache_seqlens=llm_kv_len.int(),
+                                              kv_len_hint=self.llm_kv_len_hint)
+        sh = self.shard
+        # bottom-right causal alignment only matters on the rank that owns the tail of the sequence
+        call = self.ops.sharded_prefix_attention(q, K_Cache, V_Cache, sh.local_len(llm_kv_len),
+                                                 causal=causal and sh.is_tail, kv_len_hint=sh.local_hint(self.llm_kv_len_hint))
+        return sh.attend(call)
+
     def prefill(self, hidden_states, position_embeddings):                      # :206-233
         bsz, q_len, _ = hidden_states.size()
         q, k, v = self._qkv(hidden_states, position_embeddings)
@@ -95,8 +107,7 @@ class GlideAttention(nn.Module):
                                               cache_seqlens=cache_lens.int(), kv_len_hint=self.kv_len_hint)
         else:
             q, _, _ = self._qkv(hidden_states, position_embeddings, need_kv=False)
-            attn = self.ops.kvcache_attention(q, K_Cache, V_Cache, causal=True, cache_seqlens=llm_kv_len.int(),
-                                              kv_len_hint=self.llm_kv_len_hint)
+            attn = self._cross(q, K_Cache, V_Cache, llm_kv_len, causal=True)
         return self.o_proj(attn.view(bsz, q_len, self.hidden_size))
 
     def tree_decoding(self, hidden_states, position_embeddings, cache_lens, K_Cache, V_Cache, llm_kv_len=None,
@@ -104,8 +115,7 @@ class GlideAttention(nn.Module):
         bsz, q_len, _ = hidden_states.size()
         if K_Cache is not None:
             q, _, _ = self._qkv(hidden_states, position_embeddings, need_kv=False)
-            attn = self.ops.kvcache_attention(q, K_Cache, V_Cache, causal=False, cache_seqlens=llm_kv_len.int(),
-                                              kv_len_hint=self.llm_kv_len_hint)
+            attn = self._cross(q, K_Cache, V_Cache, llm_kv_len, causal=False)
         else:
             q, k, v = self._qkv(hidden_states, position_embeddings)
             if tree_mask_bits is None:
@@ -466,8 +476,17 @@ class LlamaGlide(LlamaForCausalLM):
         all_llm_pred = self.lm_head(hidden_states).argmax(dim=-1)
         # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
         st.cache_lens += a - 1
-        acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
-            all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
+        sh = last_attn.shard
+        if sh is None:
+            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
+                all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
+        elif sh.is_tail:      # the accepted rows live in the tail owner's local cache
+            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
+                all_spec, all_llm_pred, tree_mask, sh.local_len(st.cache_lens), acc_n[-2], gamma + 1,
+                last_attn.K_Cache, last_attn.V_Cache)
+        else:
+            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
+                all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, None, None)
         st.cache_lens += 1
         # emitted tokens -> output_ids (device-side, fixed shape), EOS test on the whole buffer as the
         # reference does (:1120, G8), then ONE host read for (acc_num, eos flag)

@@ -108,7 +108,7 @@ def _check_qkv(q, k_cache, v_cache):
 
 def _desc(q, k_cache, v_cache, cache_seqlens, kv_len_hint, k_new=None, v_new=None, mask_bits=None, out=None,
           lse=None, new_mode=LS_NEW_NONE, n_new=0, n_new_cached=0, scatter_new=0, causal=False, window_left=-1,
-          n_app=0, prescale_q=False, softmax_scale=None, n_splits=0) -> AttnDesc:
+          n_app=0, prescale_q=False, softmax_scale=None, n_splits=0, timing=None) -> AttnDesc:
     b, sq, H, D = q.shape
     Hkv = k_cache.shape[2]
     d = AttnDesc()
@@ -124,6 +124,8 @@ def _desc(q, k_cache, v_cache, cache_seqlens, kv_len_hint, k_new=None, v_new=Non
     d.mask_bits = mask_bits.data_ptr() if mask_bits is not None else None
     d.out = out.data_ptr() if out is not None else None
     d.lse = lse.data_ptr() if lse is not None else None
+    if timing is not None:          # (torch.cuda.Event, torch.cuda.Event), both already created by a record()
+        d.ev_start, d.ev_stop = timing[0].cuda_event, timing[1].cuda_event
     d.b, d.sq, d.H, d.Hkv = b, sq, H, Hkv
     d.dtype = _dtype(q)
     d.new_mode = new_mode
@@ -215,7 +217,7 @@ def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1):
 
 
 def verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, last_layer: bool,
-                     softmax_scale: float = 1.0 / (128 ** 0.5), kv_len_hint: Optional[int] = None, n_splits=0):
+                     softmax_scale: float = 1.0 / (128 ** 0.5), kv_len_hint: Optional[int] = None, n_splits=0, timing=None):
     """Hybrid tree-verification attention of one target layer (K1+K2+K3 fused):
     prefix flash-decoding over ``cache[:, :cache_lens]`` + scatter of the R new K/V rows at
     ``cache_lens`` + tree-masked part + fp16 merge.  ``mask_bits`` = ``pack_tree_mask`` of
@@ -226,7 +228,7 @@ def verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, l
     out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
     d = _desc(q, k_cache, v_cache, cache_lens, _hint(cache_lens, kv_len_hint, k_cache), k_new=k_new, v_new=v_new,
               mask_bits=mask_bits, out=out, new_mode=LS_NEW_TARGET, n_new=R, scatter_new=1, prescale_q=last_layer,
-              softmax_scale=softmax_scale, n_splits=n_splits)
+              softmax_scale=softmax_scale, n_splits=n_splits, timing=timing)
     _run(d, q.device)
     return out
 
@@ -266,9 +268,11 @@ def lse_merge(parts_o: torch.Tensor, parts_lse: torch.Tensor, dtype=None, want_o
 
 # ---- multi-GPU building blocks (sequence-sharded prefix KV) -------------------------------------
 class ShardedAttnCall:
-    """Stage 1 / exchange / stage 2 of one attention call whose prefix KV is sharded by
-    sequence over ranks.  Usage: ``partial()`` -> (o32, lse) of the LOCAL
-    prefix rows; all-gather those over ranks; ``finish(parts_o, parts_lse)``."""
+    """Stage 1 / exchange / stage 2 of one attention call whose prefix KV is sharded by sequence
+    over ranks.  ``partial(sendbuf)`` writes this rank's normalised prefix partial
+    ``[o32 (b*sq*H*128) | lse (b*H*sq)]`` into ``sendbuf`` (fp32); after an all-gather of those
+    records, ``finish(gathered)`` merges the W records in rank order (deterministic, identical on
+    every rank) with the locally computed new-block part."""
 
     def __init__(self, desc: AttnDesc, out: torch.Tensor, device):
         self.d = desc
@@ -278,33 +282,38 @@ class ShardedAttnCall:
         nbytes = lib.ls_attn_workspace_bytes(C.byref(desc))
         if nbytes == 0:
             _C.check(-1, "ls_attn_workspace_bytes")
-        # the new-block part must survive until finish(): private workspace
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws = _ws.get(device, nbytes)       # stream-ordered: stage 2 runs before the next call reuses it
+        self.n_o = desc.b * desc.sq * desc.H * 128
+        self.n_lse = desc.b * desc.H * desc.sq
 
-    def partial(self) -> Tuple[torch.Tensor, torch.Tensor]:
+    @property
+    def record_floats(self) -> int:
+        return self.n_o + self.n_lse
+
+    def partial(self, sendbuf: torch.Tensor) -> torch.Tensor:
         lib = _C.load()
         d = self.d
+        assert sendbuf.dtype == torch.float32 and sendbuf.numel() >= self.record_floats and sendbuf.is_contiguous()
         _C.check(lib.ls_attn_partial(C.byref(d), self.ws.data_ptr(), self.ws.numel(), _stream()), "ls_attn_partial")
-        o32 = torch.empty((d.b, d.sq, d.H, 128), dtype=torch.float32, device=self.device)
-        lse = torch.empty((d.b, d.H, d.sq), dtype=torch.float32, device=self.device)
-        _C.check(lib.ls_attn_reduce_local(C.byref(d), self.ws.data_ptr(), self.ws.numel(), o32.data_ptr(),
-                                          lse.data_ptr(), _stream()), "ls_attn_reduce_local")
-        return o32, lse
+        _C.check(lib.ls_attn_reduce_local(C.byref(d), self.ws.data_ptr(), self.ws.numel(), sendbuf.data_ptr(),
+                                          sendbuf.data_ptr() + 4 * self.n_o, _stream()), "ls_attn_reduce_local")
+        return sendbuf
 
-    def finish(self, parts_o: torch.Tensor, parts_lse: torch.Tensor) -> torch.Tensor:
+    def finish(self, gathered: torch.Tensor) -> torch.Tensor:
+        """gathered: fp32 [W, record_floats] (row w = rank w's record)."""
         lib = _C.load()
-        parts_o = parts_o.contiguous()
-        parts_lse = parts_lse.contiguous()
-        _C.check(lib.ls_attn_finish(C.byref(self.d), parts_o.data_ptr(), parts_lse.data_ptr(), parts_o.shape[0],
-                                    self.ws.data_ptr(), self.ws.numel(), _stream()), "ls_attn_finish")
+        assert gathered.dtype == torch.float32 and gathered.is_contiguous() and gathered.shape[1] >= self.record_floats
+        W, stride = gathered.shape[0], gathered.stride(0)
+        _C.check(lib.ls_attn_finish(C.byref(self.d), gathered.data_ptr(), gathered.data_ptr() + 4 * self.n_o, W, stride,
+                                    stride, self.ws.data_ptr(), self.ws.numel(), _stream()), "ls_attn_finish")
         return self.out
 
 
 def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits, last_layer,
                              softmax_scale=1.0 / (128 ** 0.5), kv_len_hint=None) -> ShardedAttnCall:
     """Like ``verify_attention`` but ``k_cache/v_cache`` hold only this rank's prefix rows
-    (``local_lens`` valid rows); the new rows are scattered at ``local_lens`` of the LOCAL
-    cache (only the tail-owning rank's copy is ever read back as prefix)."""
+    (``local_lens`` valid rows); the new rows are scattered at ``local_lens`` of the LOCAL cache
+    (only the tail-owning rank's copy is ever read back as prefix)."""
     _dev(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits)
     _check_qkv(q, k_cache, v_cache)
     b, R, H, D = q.shape
@@ -315,13 +324,14 @@ def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask
     return ShardedAttnCall(d, out, q.device)
 
 
-def sharded_prefix_attention(q, k_cache, v_cache, local_lens, kv_len_hint=None) -> ShardedAttnCall:
-    """Non-causal prefix attention over a local KV shard (draft cross-attention, K7)."""
+def sharded_prefix_attention(q, k_cache, v_cache, local_lens, causal=False, kv_len_hint=None) -> ShardedAttnCall:
+    """Prefix attention over a local KV shard (draft cross-attention, K7).  ``causal`` only on the
+    rank that owns the tail of the sequence (all keys of the other shards precede every query)."""
     _dev(q, k_cache, v_cache, local_lens)
     _check_qkv(q, k_cache, v_cache)
     b, R, H, D = q.shape
     out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
-    d = _desc(q, k_cache, v_cache, local_lens, _hint(local_lens, kv_len_hint, k_cache), out=out)
+    d = _desc(q, k_cache, v_cache, local_lens, _hint(local_lens, kv_len_hint, k_cache), out=out, causal=causal)
     return ShardedAttnCall(d, out, q.device)
 
 

@@ -72,7 +72,7 @@ def _bottom_right_mask(sq: int, sk: int, causal: bool, window: Tuple[int, int]) 
 
 
 def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, vis: Optional[torch.Tensor],
-            scale: float) -> Tuple[torch.Tensor, torch.Tensor]:
+            scale: float, keep_f32: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """One batch element.  q [sq,H,D], k/v [sk,Hkv,D] (fp16/bf16).  Flash-style
     numerics: fp32 scores, fp32 softmax statistics, P rounded to the input dtype
     before P.V, fp32 accumulation, one division by the *unrounded* row sum, one
@@ -82,7 +82,7 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, vis: Optional[tor
     g = H // Hkv
     dt = q.dtype
     if sk == 0:       # empty key set: zeros and lse = -inf
-        return torch.zeros_like(q), torch.full((H, sq), float("-inf"), dtype=F32)
+        return torch.zeros_like(q, dtype=F32 if keep_f32 else dt), torch.full((H, sq), float("-inf"), dtype=F32)
     qf = q.float().permute(1, 0, 2)                                   # H sq D
     kf = k.float().permute(1, 0, 2).repeat_interleave(g, dim=0)       # H sk D
     vf = v.float().permute(1, 0, 2).repeat_interleave(g, dim=0)
@@ -95,7 +95,8 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, vis: Optional[tor
     l = p.sum(dim=-1, keepdim=True)
     o = torch.matmul(p.to(dt).float(), vf) / torch.where(l == 0, torch.ones_like(l), l)
     lse = (m_safe + torch.log(l)).squeeze(-1)                          # H sq  (-inf for empty rows)
-    return o.permute(1, 0, 2).to(dt).contiguous(), lse
+    o = o.permute(1, 0, 2).contiguous()
+    return (o if keep_f32 else o.to(dt)), lse
 
 
 # --------------------------------------------------------------------------- #
@@ -114,7 +115,7 @@ def flash_attention(q, k, v, causal=False, window_size=(-1, -1), softmax_scale=N
 
 
 def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, causal=False,
-                      window_size=(-1, -1), return_softmax_lse=False, softmax_scale=None):
+                      window_size=(-1, -1), return_softmax_lse=False, softmax_scale=None, keep_f32=False):
     """``flash_attn_with_kvcache`` as the reference calls it:
     target decode ``llama.py:324`` (append, causal); target verify prefix
     ``llama.py:385`` (no append, non-causal, LSE); draft self step 0
@@ -142,7 +143,7 @@ def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, c
         else:
             sk = L
         vis = _bottom_right_mask(sq, sk, causal, window_size)
-        o, lse = _attend(q[i], k_cache[i, :sk], v_cache[i, :sk], vis, scale)
+        o, lse = _attend(q[i], k_cache[i, :sk], v_cache[i, :sk], vis, scale, keep_f32=keep_f32)
         outs.append(o)
         lses.append(lse)
     out = torch.stack(outs, 0)

@@ -68,3 +68,53 @@ def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1):
     k_cache[:, :L] = k
     v_cache[:, :L] = v
     return ref_ops.flash_attention(q, k, v, causal=True, window_size=(window_left, -1))
+
+
+class _ShardCall:
+    """CPU counterpart of longspec_amd.ops.ShardedAttnCall (partial -> exchange -> finish)."""
+    device = "cpu"
+
+    def __init__(self, q, k_cache, v_cache, local_lens, causal=False, verify=None):
+        self.q, self.kc, self.vc, self.lens, self.causal, self.verify = q, k_cache, v_cache, local_lens, causal, verify
+        b, sq, H, D = q.shape
+        self.n_o, self.n_lse = b * sq * H * D, b * H * sq
+        self.record_floats = self.n_o + self.n_lse
+
+    def partial(self, send):
+        o, lse = ref_ops.kvcache_attention(self.q, self.kc, self.vc, cache_seqlens=self.lens, causal=self.causal,
+                                           return_softmax_lse=True, keep_f32=True)
+        send[:self.n_o] = o.reshape(-1)
+        send[self.n_o:self.n_o + self.n_lse] = lse.reshape(-1)
+        return send
+
+    def finish(self, gathered):
+        b, sq, H, D = self.q.shape
+        W = gathered.shape[0]
+        outs = []
+        for z in range(b):
+            parts_o = [gathered[w, :self.n_o].view(b, sq, H, D)[z] for w in range(W)]
+            parts_l = [gathered[w, self.n_o:self.n_o + self.n_lse].view(b, H, sq)[z] for w in range(W)]
+            outs.append(ref_ops.lse_merge(parts_o, parts_l))
+        o32 = torch.stack([o for o, _ in outs], 0)
+        lse = torch.stack([l for _, l in outs], 0)
+        prefix_o = o32.to(self.q.dtype)
+        if self.verify is None:
+            return prefix_o
+        k_new, v_new, mask, last_layer, scale = self.verify
+        R = self.q.shape[1]
+        for z in range(b):
+            L = int(self.lens[z])
+            self.kc[z, L:L + R] = k_new[z]
+            self.vc[z, L:L + R] = v_new[z]
+        cur, w = ref_ops.target_tree_part(self.q, k_new, v_new, mask, lse, last_layer, scale)
+        one = torch.ones((), dtype=self.q.dtype)
+        return prefix_o * w + cur * (one - w)
+
+
+def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits, last_layer,
+                             softmax_scale=1 / (128 ** 0.5), kv_len_hint=None):
+    return _ShardCall(q, k_cache, v_cache, local_lens, verify=(k_new, v_new, mask_bits, last_layer, softmax_scale))
+
+
+def sharded_prefix_attention(q, k_cache, v_cache, local_lens, causal=False, kv_len_hint=None):
+    return _ShardCall(q, k_cache, v_cache, local_lens, causal=causal)

@@ -46,7 +46,7 @@ def test_attn_desc_layout_matches_header():
             tail = tail.replace(kw, " ")
         fields += [f.strip() for f in tail.split(",") if f.strip()]
     assert fields == [f[0] for f in _C.AttnDesc._fields_]
-    assert ctypes.sizeof(_C.AttnDesc) == 9 * 8 + 16 * 4 + 4 + 4 + 12 * 8
+    assert ctypes.sizeof(_C.AttnDesc) == 11 * 8 + 16 * 4 + 4 + 4 + 12 * 8
 
 
 def test_ops_refuse_cpu_tensors():

@@ -344,8 +344,13 @@ def test_full_size_properties(ops, L):
                    out=torch.empty_like(qg))
     d2 = ops._desc(qg, kc[:, h:], vc[:, h:], torch.tensor([L - h], dtype=torch.int32, device=DEV), L - h,
                    out=torch.empty_like(qg))
-    parts = [ops.ShardedAttnCall(d, torch.empty_like(qg), qg.device).partial() for d in (d1, d2)]
-    out, _, lse = ops.lse_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), dtype=torch.float16)
+    recs = []
+    for d in (d1, d2):
+        call = ops.ShardedAttnCall(d, torch.empty_like(qg), qg.device)
+        recs.append(call.partial(torch.empty(call.record_floats, dtype=torch.float32, device=DEV)).clone())
+    n_o = R * H * 128
+    out, _, lse = ops.lse_merge(torch.stack([r[:n_o].view(1, R, H, 128) for r in recs]),
+                                torch.stack([r[n_o:].view(1, H, R) for r in recs]), dtype=torch.float16)
     assert (out.float() - o_full.float()).abs().max().item() <= 5e-4
     assert (lse - lse_full).abs().max().item() <= 2e-5
     # (3) dense fp32 reference on the GPU, 4 heads at a time
