@@ -73,6 +73,8 @@ def build_model(cfg, device, agreement, seed):
                 p.fill_(1.0)
             elif name.endswith(".bias"):
                 p.zero_()
+            elif name.endswith("embed_tokens.weight"):
+                p.normal_(0.0, 1.0, generator=g)          # unit-scale residual stream: branch outputs are O(agreement)
             else:
                 p.normal_(0.0, 0.02, generator=g)
                 if name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
@@ -158,7 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="llama3-8b-262k", choices=sorted(MODELS))
     ap.add_argument("--prefix-per-gpu", type=int, default=16384)
-    ap.add_argument("--agreement", type=float, default=0.05)
+    ap.add_argument("--agreement", type=float, default=0.02)
     ap.add_argument("--vanilla-steps", type=int, default=16)
     ap.add_argument("--cpu-sample-calls", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -69,6 +69,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64: import torch FIRST so that this library binds to the
+    # HIP runtime instance torch uses (device memory, streams and events are shared with it)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the MI355X HIP extension is required (no CPU/PyTorch fallback exists). "

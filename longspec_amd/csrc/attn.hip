@@ -57,7 +57,6 @@ struct AttnK {
     int has_new, new_mode, n_new, n_new_cached, mask_words, scatter_new, prescale_q;
     int causal, window_left, n_app;
     int n_splits, row_chunks, rows_per_chunk;
-    int debug;        // LS_DEBUG experiments: 1 = skip compute, 2 = skip DMA
     float scale;
     long q_sb, q_ss, q_sh;
     long kc_sb, kc_ss, kc_sh;
@@ -368,9 +367,8 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
         for (int t = t_from; t < t_to; ++t) {
             const int buf = (t - t_begin) & 1;
             __syncthreads();                      // tile t landed (vmcnt(0) + barrier); buffer buf^1 is free
-            if (t + 1 < t_end && !(p.debug & 2)) dma(t + 1, buf ^ 1);
+            if (t + 1 < t_end) dma(t + 1, buf ^ 1);
             const unsigned kb_a = x.smem_a + buf * BUF;               // K tile, V tile follows at + TILE*ROWB
-            if (p.debug & 1) continue;
 #pragma unroll
             for (int blk = 0; blk < TKW / 32; ++blk) {
                 const int krow0 = x.ks * TKW + blk * 32;
@@ -891,7 +889,6 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.row_chunks = c.row_chunks;
     k.rows_per_chunk = c.rows_per_chunk;
     k.scale = d->softmax_scale;
-    { const char* e = getenv("LS_DEBUG"); k.debug = e ? atoi(e) : 0; }
     k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
     k.kn_sb = d->kn_stride_b; k.kn_ss = d->kn_stride_s; k.kn_sh = d->kn_stride_h;
