@@ -15,19 +15,23 @@
 // MI355X mapping.  All g = H/Hkv query heads of a kv head and all sq query rows are
 // packed into one M = g*sq row block that shares every K/V byte read from HBM (GQA-4,
 // 74 rows: 296 flop per KV byte, i.e. right at the MFMA/HBM ridge).  A workgroup is
-// 4 waves = one wave per SIMD with the whole 512-entry register file: each wave owns
-// QT tiles of 16 rows and computes, per 32-key block,
+// RB x KS waves: RB row blocks of QT*16 rows (QT = 2: 32 rows per wave, 10 waves for the 296
+// rows of a Llama-3 verify pass) times KS key slices (small row counts).  2-3 waves share a
+// SIMD, so LDS, MFMA and VALU latencies of one wave are covered by the others.  Per 32-key
+// block a wave computes
 //     S^T[key][row] = K . Q^T          (mfma_f32_16x16x32: A = K fragment,  B = Q^T fragment)
 //     O^T[d][row]  += V^T . P^T        (A = V^T via ds_read_b64_tr_b16,     B = P^T = S^T's own layout)
 // Both products are "transposed" so that a lane always owns ONE query row (lane&15):
 // the soft-max running max / sum / rescale are per-lane scalars (two xor-shuffles per
 // row for the max), P feeds the second MFMA straight from registers, and nothing but
 // K/V tiles ever goes through LDS.  K/V tiles go HBM -> LDS directly (global_load_lds,
-// 16 bytes per lane, 256 contiguous bytes per key and kv head, no staging registers)
-// into a double buffer: the DMA of tile t+1 is in flight while tile t is multiplied,
-// one barrier per tile.  The LDS image is XOR-swizzled (applied on the per-lane SOURCE
-// address, the LDS destination of the DMA being lane-linear) so that both the
-// ds_read_b128 K-fragment reads and the transposing V reads are bank-conflict free.
+// 16 bytes per lane, 256 contiguous bytes per key and kv head, no staging registers) into a
+// ring of up to 4 tiles: with HBM round trips of ~3 us under load a single tile in flight
+// caps a CU at ~10 GB/s, so tiles t+1..t+3 are in flight while tile t is multiplied
+// (counted s_waitcnt vmcnt + raw s_barrier, one barrier per tile).  The LDS image is
+// XOR-swizzled (applied on the per-lane SOURCE address, the LDS destination of the DMA being
+// lane-linear) so that both the ds_read_b128 K-fragment reads and the transposing V reads are
+// bank-conflict free.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -38,6 +42,7 @@ namespace {
 constexpr int D = LS_HEAD_DIM;      // 128
 constexpr int ROWB = D * 2;         // bytes per key row (fp16/bf16)
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr int MAX_THREADS = 768;    // up to 12 waves per workgroup
 
 struct AttnK {
     const void* q;
@@ -57,6 +62,9 @@ struct AttnK {
     int has_new, new_mode, n_new, n_new_cached, mask_words, scatter_new, prescale_q;
     int causal, window_left, n_app;
     int n_splits, row_chunks, rows_per_chunk;
+    // workgroup shape (host-chosen): RB row blocks x KS key slices waves; a tile = `tile` keys
+    // (KS * bpw * 32), `nstages` tiles of LDS ring, DMA by the first `nd` waves, `pp` pieces each
+    int RB, KS, tile, bpw, nstages, nd, pp;
     float scale;
     long q_sb, q_ss, q_sh;
     long kc_sb, kc_ss, kc_sh;
@@ -71,25 +79,25 @@ struct WaveAcc {
 };
 
 // ---- LDS tile layout -------------------------------------------------------------
-// K (and the per-wave Q image): row-major [row][128], 16-byte slot s stored at slot s ^ (row & 15)
+// K: row-major [row][128], 16-byte slot s stored at slot s ^ (row & 15)
 // V: row-major [key][128], 16-byte slot s stored at slot s ^ ((key & 7) << 1)
-// All fragment addresses are  <per-lane table entry> + <wave-uniform base> + <immediate>:
-//   ktbl[k4] = l15*256 + (((k4*4 + g4) ^ l15) << 4)            rows 16-aligned => (row & 15) == l15
-//   vtbl[dt] = (g4*4 + l15/4)*256 + (((dt*2 + (l15&3)/2) ^ ((key & 7) << 1)) << 4) + (l15&1)*8
-// so the hot loop carries 12 address registers instead of one per (buffer, block, fragment).
+// Fragment addresses (rows 16-aligned => (row & 15) == l15), written so that the per-lane part
+// is ONE register per operand and the k4 / dt dependence is an XOR on the fly:
+//   K/Q fragment k4 :  kb + ((k4 ^ (l15 >> 2)) << 6),   kb = l15*256 + ((g4 ^ (l15 & 3)) << 4)
+//   V^T fragment dt :  vb + ((dt ^ kk) << 5),           vb = key*256 + (((l15 >> 1) & 1) << 4) + ((l15 & 1) << 3)
+//                      key = g4*4 + (l15 >> 2), kk = key & 7
 struct LaneTbl {
-    int k[4];
-    int v[8];
+    int kb, kx;      // K: base, xor key (l15 >> 2)
+    int vb, vx;      // V: base, xor key (key & 7)
 };
 
 __device__ __forceinline__ LaneTbl make_lane_tbl(int l15, int g4) {
     LaneTbl t;
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) t.k[k4] = l15 * ROWB + (((k4 * 4 + g4) ^ l15) << 4);
+    t.kb = l15 * ROWB + ((g4 ^ (l15 & 3)) << 4);
+    t.kx = l15 >> 2;
     const int key = g4 * 4 + (l15 >> 2);
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-        t.v[dt] = key * ROWB + (((dt * 2 + ((l15 & 3) >> 1)) ^ ((key & 7) << 1)) << 4) + ((l15 & 1) << 3);
+    t.vb = key * ROWB + (((l15 >> 1) & 1) << 4) + ((l15 & 1) << 3);
+    t.vx = key & 7;
     return t;
 }
 
@@ -100,33 +108,29 @@ __device__ __forceinline__ V8 lds_read16(unsigned addr) {
 }
 
 // S^T for one 32-key block: s[kt][qt], kt = 16-key tile.  kbase = LDS byte address of the
-// block's first key row; qbase = LDS byte address of this wave's Q image (QLDS) -- when the
-// 160 accumulator registers of QT >= 5 leave no room for the 80 registers of Q^T fragments
-// they are re-read from LDS (ds_read_b128, same swizzle as K) instead of being spilled.
-template <typename E, int QT, bool QLDS>
-__device__ __forceinline__ void qk_block(f32x4 (&s)[2][QT], const typename E::V8 (&qf)[QLDS ? 1 : QT][4],
-                                         const LaneTbl& tb, unsigned qbase, unsigned kbase) {
+// block's first key row.
+template <typename E, int QT>
+__device__ __forceinline__ void qk_block(f32x4 (&s)[2][QT], const typename E::V8 (&qf)[QT][4], const LaneTbl& tb,
+                                         unsigned kbase) {
+    // keep the 4 fragment addresses out of loop-invariant hoisting (they would be precomputed per
+    // ring slot and spilled): the xor key is made opaque once per block
+    int kx = tb.kx;
+    asm volatile("" : "+v"(kx));
+    const unsigned kb = kbase + tb.kb;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
-        const unsigned ka = kbase + tb.k[k4];
+        const unsigned ka = kb + ((k4 ^ kx) << 6);
         typename E::V8 kf[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) kf[kt] = lds_read16<typename E::V8>(ka + kt * 16 * ROWB);
-        const unsigned qa = qbase + tb.k[k4];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            typename E::V8 qv;
-            if (QLDS)
-                qv = lds_read16<typename E::V8>(qa + qt * 16 * ROWB);
-            else
-                qv = qf[QLDS ? 0 : qt][k4];
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[kt], qv, s[kt][qt]);
-        }
+            for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[kt], qf[qt][k4], s[kt][qt]);
     }
 }
 
@@ -140,9 +144,12 @@ template <typename E, int QT>
 __device__ __forceinline__ void pv_block(WaveAcc<E, QT>& w, const typename E::V8 (&pf)[QT], const LaneTbl& tb,
                                          unsigned vbase) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    int vx = tb.vx;
+    asm volatile("" : "+v"(vx));           // see qk_block
+    const unsigned vb = vbase + tb.vb;
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
-        const unsigned va = vbase + tb.v[dt];
+        const unsigned va = vb + ((dt ^ vx) << 5);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
         union {
@@ -161,11 +168,11 @@ __device__ __forceinline__ void pv_block(WaveAcc<E, QT>& w, const typename E::V8
 //   SAFE = true : textbook online soft-max -- block row-max, running max m, rescale of O and l
 //                 whenever a row's max grows.
 //   SAFE = false: the running max is used as a FIXED reference: p = 2^(s*c - m*c) without looking
-//                 at the block's own max, so the 160 accumulator registers are touched by MFMAs
-//                 only.  Exact as long as no p overflows fp16 (s - m < ~11 in natural-log units,
-//                 i.e. a key scoring e^11 above everything seen so far); the largest p is tracked
-//                 in `pmax` and the caller re-runs the split with SAFE = true if it ever gets
-//                 near the fp16 range.  (lse = m*scale + ln(l) holds for any reference m.)
+//                 at the block's own max, so the accumulator registers are touched by MFMAs only.
+//                 Exact as long as no p overflows fp16 (s - m < ~11 in natural-log units, i.e. a
+//                 key scoring e^11 above everything seen so far); the largest p is tracked in
+//                 `pmax` and the caller re-runs the split with SAFE = true if it ever gets near the
+//                 fp16 range.  (lse = m*scale + ln(l) holds for any reference m.)
 template <typename E, int QT, bool SAFE>
 __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], float c, const LaneTbl& tb,
                                              unsigned vbase, float& pmax) {
@@ -206,17 +213,17 @@ __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)
 }
 
 // ---- HBM -> LDS tile DMA -----------------------------------------------------------------
-// One wave-instruction moves 64 x 16 B = 4 key rows.  LDS slot `pos` of row `key` receives
-// global chunk pos ^ swz(key) (the swizzle is an involution, so the same XOR is used on reads).
+// One wave-instruction ("piece") moves 64 x 16 B = 4 key rows of K or of V.  LDS slot `pos` of
+// row `key` receives global chunk pos ^ swz(key) (an involution: the same XOR is used on reads).
+// A tile of `tile` keys is tile/4 K pieces + tile/4 V pieces; DMA wave w (< nd) issues the key
+// groups w, w + nd, ... (pp/2 of them, K and V each).
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
 
-template <int TILE, typename F>
-__device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, F&& row_ptr) {
+template <typename F>
+__device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, int nd, int ngroups, F&& row_ptr) {
     const int kq = lane >> 4, pos = lane & 15;
-#pragma unroll
-    for (int i = 0; i < TILE / 16; ++i) {
-        const int grp = i * 4 + wave;
+    for (int grp = wave; grp < ngroups; grp += nd) {
         const int key = grp * 4 + kq;
         const char* kp;
         const char* vp;
@@ -226,31 +233,37 @@ __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int l
     }
 }
 
-// ---- the kernel -----------------------------------------------------------------------
-// Common per-wave setup, shared by the two paths below.
-template <typename E, int RB, int KS, int QT, int TKW>
+// wait until at most n of this wave's vector-memory operations (= DMA pieces) are outstanding
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- per-wave context -------------------------------------------------------------------
+template <typename E, int QT>
 struct Ctx {
-    static constexpr int TILE = KS * TKW;            // keys per workgroup iteration
-    static constexpr int BUF = 2 * TILE * ROWB;      // bytes of one (K,V) buffer
-    static constexpr bool QLDS = QT >= 5;            // Q^T fragments in LDS instead of registers
     int tid, lane, wave, rb, ks, l15, g4, bi, kvh, chunk, L, sk, row0;
     float c;
     int rrow[QT];
-    unsigned smem_a, qbase;
+    unsigned smem_a;
     LaneTbl tb;
     const char* kc_base;
     const char* vc_base;
     long kc_row;
 };
 
-template <typename E, int RB, int KS, int QT, int TKW>
-__device__ __forceinline__ void ctx_init(Ctx<E, RB, KS, QT, TKW>& x, const AttnK& p, char* smem) {
-    using C = Ctx<E, RB, KS, QT, TKW>;
+template <typename E, int QT>
+__device__ __forceinline__ void ctx_init(Ctx<E, QT>& x, const AttnK& p, char* smem) {
     x.tid = threadIdx.x;
     x.lane = x.tid & 63;
     x.wave = __builtin_amdgcn_readfirstlane(x.tid >> 6);
-    x.rb = x.wave / KS;
-    x.ks = x.wave % KS;
+    x.rb = x.wave / p.KS;
+    x.ks = x.wave % p.KS;
     x.l15 = x.lane & 15;
     x.g4 = x.lane >> 4;
     x.bi = blockIdx.z;
@@ -268,19 +281,15 @@ __device__ __forceinline__ void ctx_init(Ctx<E, RB, KS, QT, TKW>& x, const AttnK
     }
     typedef __attribute__((address_space(3))) char lds_char;
     x.smem_a = (unsigned)(uintptr_t)(lds_char*)smem;          // LDS byte address of the carve
-    // LDS: [2 x (K tile, V tile)] [Q image of each row block (QLDS only)]
-    x.qbase = x.smem_a + 2 * C::BUF + x.rb * (QT * 16 * ROWB);
     x.tb = make_lane_tbl(x.l15, x.g4);
     x.kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)x.bi * p.kc_sb + (long)x.kvh * p.kc_sh) * 2;
     x.vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)x.bi * p.kc_sb + (long)x.kvh * p.kc_sh) * 2;
     x.kc_row = p.kc_ss * 2;
 }
 
-// Q^T fragments (B operand of the first product): registers, or the row block's LDS image.
-template <typename E, int RB, int KS, int QT, int TKW>
-__device__ __forceinline__ void load_q(const Ctx<E, RB, KS, QT, TKW>& x, const AttnK& p, bool prescale,
-                                       typename E::V8 (&qf)[(QT >= 5) ? 1 : QT][4]) {
-    constexpr bool QLDS = QT >= 5;
+// Q^T fragments (B operand of the first product), in registers.
+template <typename E, int QT>
+__device__ __forceinline__ void load_q(const Ctx<E, QT>& x, const AttnK& p, bool prescale, typename E::V8 (&qf)[QT][4]) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int m = x.row0 + qt * 16 + x.l15;
@@ -294,14 +303,7 @@ __device__ __forceinline__ void load_q(const Ctx<E, RB, KS, QT, TKW>& x, const A
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
             }
-            if (QLDS) {
-                // the image of a row block is written by its ks == 0 wave; the first __syncthreads()
-                // of the tile loop orders these ds_writes before any wave's ds_read
-                if (x.ks == 0)
-                    *(__attribute__((address_space(3))) typename E::V8*)(uintptr_t)(x.qbase + qt * 16 * ROWB + x.tb.k[k4]) = v;
-            } else {
-                qf[QLDS ? 0 : qt][k4] = v;
-            }
+            qf[qt][k4] = v;
         }
     }
 }
@@ -317,15 +319,15 @@ __device__ __forceinline__ void acc_init(WaveAcc<E, QT>& w) {
     }
 }
 
-// ================= prefix split: tiles [t_begin, t_end) of TILE keys =====================
-template <typename E, int RB, int KS, int QT, int TKW>
+// ================= prefix split: tiles [t_begin, t_end) of `tile` keys =====================
+template <typename E, int QT>
 __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int split) {
-    using C = Ctx<E, RB, KS, QT, TKW>;
-    constexpr int TILE = C::TILE, BUF = C::BUF;
-    constexpr bool QLDS = C::QLDS;
+    using C = Ctx<E, QT>;
     C x;
     ctx_init(x, p, smem);
     const int L = x.L, sk = x.sk, l15 = x.l15, g4 = x.g4;
+    const int TILE = p.tile, S = p.nstages;
+    const int STAGE = 2 * TILE * ROWB;            // bytes of one (K,V) stage
     // visible prefix key range of row r (flash-attn bottom-right alignment):
     //   lo(r) = max(0, r + sk - sq - window_left), hi(r) = min(L, r + sk - sq + 1) if causal else L
     int lo_min = 0, lo_max = 0, hi_min = L, hi_max = L;
@@ -337,8 +339,8 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
         hi_min = max(0, min(L, sk - p.sq + 1));
         hi_max = max(0, min(L, sk));
     }
-    typename E::V8 qf[QLDS ? 1 : QT][4];
-    load_q<E, RB, KS, QT, TKW>(x, p, false, qf);
+    typename E::V8 qf[QT][4];
+    load_q<E, QT>(x, p, false, qf);
     WaveAcc<E, QT> w;
 
     const int t0 = lo_min / TILE;
@@ -347,9 +349,11 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
     const int t_begin = t0 + split * tps;
     const int t_end = min(t_begin + tps, t1);
     const int last_key = hi_max - 1;
-    auto dma = [&](int tile, int buf) {
-        char* bK = smem + buf * BUF;
-        tile_dma<TILE>(bK, bK + TILE * ROWB, x.wave, x.lane, [&](int key, const char*& kp, const char*& vp) {
+    const bool dma_wave = x.wave < p.nd;
+    auto dma = [&](int tile) {              // tile -> ring slot (tile - t_begin) % S
+        if (!dma_wave) return;
+        char* bK = smem + ((tile - t_begin) % S) * STAGE;
+        tile_dma(bK, bK + TILE * ROWB, x.wave, x.lane, p.nd, TILE / 4, [&](int key, const char*& kp, const char*& vp) {
             const long ka = min(tile * TILE + key, last_key);   // tail rows: re-read the last valid key (masked below)
             kp = x.kc_base + ka * x.kc_row;
             vp = x.vc_base + ka * x.kc_row;
@@ -358,24 +362,26 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
     // Three tile ranges share one DMA pipeline:  [t_begin, tA) and [tB, t_end) touch a range edge
     // (window / causal / tail of the cache) or prime the running max and run the textbook online
     // soft-max with masks; [tA, tB) are interior tiles and run the fixed-reference form whose loop
-    // body is branch-free: DMA issue, barrier, 2 x (QK^T, exp2, P.V).
+    // body is branch-free: wait, barrier, DMA issue, bpw x (QK^T, exp2, P.V).
     // attempt 1 (only if some p came close to the fp16 range): textbook form everywhere.
-    int* redo_flag = reinterpret_cast<int*>(smem + 2 * BUF + (QLDS ? RB * QT * 16 * ROWB : 0));
+    int* redo_flag = reinterpret_cast<int*>(smem + S * STAGE);
     float pmax = 0.f;
     auto run_tiles = [&](int t_from, int t_to, auto safe_tag) {
         constexpr bool SAFE = decltype(safe_tag)::value;
         for (int t = t_from; t < t_to; ++t) {
-            const int buf = (t - t_begin) & 1;
-            __syncthreads();                      // tile t landed (vmcnt(0) + barrier); buffer buf^1 is free
-            if (t + 1 < t_end) dma(t + 1, buf ^ 1);
-            const unsigned kb_a = x.smem_a + buf * BUF;               // K tile, V tile follows at + TILE*ROWB
-#pragma unroll
-            for (int blk = 0; blk < TKW / 32; ++blk) {
-                const int krow0 = x.ks * TKW + blk * 32;
+            // tile t landed once at most the pieces of the younger tiles in flight are outstanding
+            const int younger = min(S - 2, t_end - 1 - t);
+            wait_vmcnt(dma_wave ? younger * p.pp : 0);
+            __builtin_amdgcn_s_barrier();          // every wave's pieces of tile t landed; tile t-1 fully consumed
+            if (t + S - 1 < t_end) dma(t + S - 1);  // refill the slot tile t-1 just vacated
+            const unsigned kb_a = x.smem_a + ((t - t_begin) % S) * STAGE;      // K tile; V tile follows at + TILE*ROWB
+#pragma unroll 1
+            for (int blk = 0; blk < p.bpw; ++blk) {
+                const int krow0 = (x.ks * p.bpw + blk) * 32;
                 const int ka0 = t * TILE + krow0;
                 if (SAFE && (ka0 >= hi_max || ka0 + 32 <= lo_min)) continue;   // wave-uniform
                 f32x4 s[2][QT];
-                qk_block<E, QT, QLDS>(s, qf, x.tb, x.qbase, kb_a + krow0 * ROWB);
+                qk_block<E, QT>(s, qf, x.tb, kb_a + krow0 * ROWB);
                 if (SAFE && !(ka0 >= lo_max && ka0 + 32 <= hi_min)) {          // block touches a range edge
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
@@ -398,7 +404,7 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
         acc_init<E, QT>(w);
         pmax = 0.f;
         if (x.tid == 0) *redo_flag = 0;
-        if (t_begin < t_end) dma(t_begin, 0);
+        for (int i = 0; i < S - 1 && t_begin + i < t_end; ++i) dma(t_begin + i);      // S-1 tiles in flight
         // interior tiles: whole tile inside [lo_max, hi_min); the first tile always primes the max
         int tA = max(t_begin + 1, (lo_max + TILE - 1) / TILE);
         int tB = min(t_end, hi_min / TILE);
@@ -414,14 +420,14 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
         if (!redo) break;
     }
     // ---- write the (normalised) partial ------------------------------------------
-    const int part = split * KS + x.ks;
+    const int part = split * p.KS + x.ks;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const float lt = wave_xor_sum_16_32(w.l[qt]);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         const float lse = lt > 0.f ? w.m[qt] * p.scale + __logf(lt) : -INFINITY;
         const int m = x.row0 + qt * 16 + l15;
-        if (m < p.M) {
+        if (m < p.M && x.rb < p.RB) {
             const int head = x.kvh * p.g + m / p.sq;
             float* op = p.parts_o + ((((long)part * p.b + x.bi) * p.sq + x.rrow[qt]) * p.H + head) * D + g4 * 4;
 #pragma unroll
@@ -434,43 +440,48 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
 // ===================== new key block (tree / appended tokens) ===========================
 // Kept out of line: a handful of workgroups run it once per launch, and its three
 // numerics variants must not weigh on the register allocation of the streaming loop above.
-template <typename E, int RB, int KS, int QT, int TKW>
-__device__ __attribute__((noinline)) void new_block_path(const AttnK p, char* smem) {
-    // (by value: the caller's copy lives on the cold branch only, so the streaming path keeps
-    //  its parameters in scalar registers)
-    using C = Ctx<E, RB, KS, QT, TKW>;
-    constexpr int TILE = C::TILE;
-    constexpr bool QLDS = C::QLDS;
+typedef __attribute__((address_space(4))) const AttnK KernArgAttnK;   // the kernel's argument block (constant memory)
+
+template <typename E, int QT, int MODE>
+__device__ __attribute__((noinline)) void new_block_path(KernArgAttnK* pk, char* smem) {
+    // The parameters are re-read from the kernel-argument segment (scalar loads -> SGPRs): passing the
+    // 300-byte block by value would put it on the stack and turn every field access into a scratch load.
+    // MODE (= p.new_mode) is a template parameter so that each numerics variant carries only its own state.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const AttnK p = *pk;
+#else
+    const AttnK p = {};   // host pass of the single-source compile: never executed
+    (void)pk;
+#endif
+    using C = Ctx<E, QT>;
     C x;
     ctx_init(x, p, smem);
     const int L = x.L, l15 = x.l15, g4 = x.g4, tid = x.tid, bi = x.bi, kvh = x.kvh;
     const float c = x.c;
-    typename E::V8 qf[QLDS ? 1 : QT][4];
-    load_q<E, RB, KS, QT, TKW>(x, p, p.new_mode == LS_NEW_TARGET && p.prescale_q, qf);
-    WaveAcc<E, QT> w;
-    acc_init<E, QT>(w);
+    const int TILE = p.tile;
+    typename E::V8 qf[QT][4];
+    load_q<E, QT>(x, p, MODE == LS_NEW_TARGET && p.prescale_q, qf);
     const char* kc_base = x.kc_base;
     const char* vc_base = x.vc_base;
     const long kc_row = x.kc_row;
     const int row0 = x.row0;
-    const int chunk = x.chunk;
-    const int ks = x.ks;
     const int (&rrow)[QT] = x.rrow;
     const LaneTbl& tb = x.tb;
-    const unsigned smem_a = x.smem_a, qbase = x.qbase;
-    const int wave = x.wave, lane = x.lane;
+    const unsigned smem_a = x.smem_a;
     const int n_new = p.n_new;
     const int nblk = (n_new + 31) / 32;
     const char* kn_base = reinterpret_cast<const char*>(p.k_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
     const char* vn_base = reinterpret_cast<const char*>(p.v_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
     const long kn_row = p.kn_ss * 2;
+    const int nthreads = blockDim.x;
+    const int nwaves = nthreads >> 6;
 
     // scatter the new K/V rows into the caches (llama.py:396-399, llama_glide.py:312-315)
-    if (p.scatter_new && chunk == 0) {
+    if (p.scatter_new && x.chunk == 0) {
         char* kw = reinterpret_cast<char*>(p.k_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
         char* vw = reinterpret_cast<char*>(p.v_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
         const int n_rows = n_new - p.n_new_cached;
-        for (int idx = tid; idx < n_rows * 16; idx += 256) {
+        for (int idx = tid; idx < n_rows * 16; idx += nthreads) {
             const int i = idx >> 4, ch = idx & 15;
             const long dst = (long)(L + p.n_new_cached + i) * kc_row;
             reinterpret_cast<uint4*>(kw + dst)[ch] = reinterpret_cast<const uint4*>(kn_base + (long)i * kn_row)[ch];
@@ -478,143 +489,166 @@ __device__ __attribute__((noinline)) void new_block_path(const AttnK p, char* sm
         }
     }
 
-    const bool worker = (ks == 0);   // the few new keys are not split across waves
-    const int npass = (p.new_mode == LS_NEW_TARGET) ? 3 : 1;
-    float pmax_unused = 0.f;
-    float tmax[QT], tsum[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        tmax[qt] = -INFINITY;
-        tsum[qt] = 0.f;
-    }
+    // ---- all new keys -> LDS in one go: the ring holds nstages*tile >= 256 keys; K at [0, cap), V behind it
+    const int cap = p.nstages * TILE;                 // keys
+    const int nkeys = nblk * 32;                      // <= cap (checked on the host)
     char* ldsK = smem;
-    char* ldsV = smem + TILE * ROWB;
-    for (int pass = 0; pass < npass; ++pass) {
-        for (int j0 = 0; j0 < nblk * 32; j0 += TILE) {
-            __syncthreads();       // previous tile fully consumed
-            tile_dma<TILE>(ldsK, ldsV, wave, lane, [&](int key, const char*& kp, const char*& vp) {
-                const int j = min(j0 + key, n_new - 1);            // tail rows: masked by zero bits
-                if (j < p.n_new_cached) {
-                    kp = kc_base + (long)(L + j) * kc_row;
-                    vp = vc_base + (long)(L + j) * kc_row;
-                } else {
-                    kp = kn_base + (long)(j - p.n_new_cached) * kn_row;
-                    vp = vn_base + (long)(j - p.n_new_cached) * kn_row;
-                }
-            });
-            __syncthreads();       // tile landed
-            if (!worker) continue;
+    char* ldsV = smem + cap * ROWB;
+    tile_dma(ldsK, ldsV, x.wave, x.lane, nwaves, nkeys / 4, [&](int key, const char*& kp, const char*& vp) {
+        const int j = min(key, n_new - 1);            // tail rows: masked by zero bits
+        if (j < p.n_new_cached) {
+            kp = kc_base + (long)(L + j) * kc_row;
+            vp = vc_base + (long)(L + j) * kc_row;
+        } else {
+            kp = kn_base + (long)(j - p.n_new_cached) * kn_row;
+            vp = vn_base + (long)(j - p.n_new_cached) * kn_row;
+        }
+    });
+    const bool worker = (x.ks == 0) && (x.rb < p.RB);   // the few new keys are not split across key slices
+    __syncthreads();                                   // keys landed (vmcnt(0) + barrier)
+    if (!worker) return;
+    const unsigned vbase0 = smem_a + cap * ROWB;
+    auto mask_word = [&](int qt, int blk) -> uint32_t {
+        const int m = row0 + qt * 16 + l15;
+        return m < p.M ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + blk] : 0u;
+    };
+
+    WaveAcc<E, QT> w;
+    float lse_out[QT];
+    float scale_o[QT];
+    if (MODE != LS_NEW_TARGET) {
+        // ---- blocked online soft-max with base-2 exponentials: flash-attn append semantics, and the Triton tree
+        // kernel's loop (BLOCK_N = 32, triton_tree_attn.py:191-235)
+        acc_init<E, QT>(w);
+        float pmax_unused = 0.f;
 #pragma unroll 1
-            for (int krow0 = 0; krow0 < TILE; krow0 += 32) {
-                if (j0 + krow0 >= nblk * 32) break;
-                const int blk = (j0 + krow0) >> 5;
-                uint32_t bits[QT];
+        for (int blk = 0; blk < nblk; ++blk) {
+            uint32_t bits[QT];
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const int m = row0 + qt * 16 + l15;
-                    bits[qt] = m < p.M ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + blk] : 0u;
+            for (int qt = 0; qt < QT; ++qt) bits[qt] = mask_word(qt, blk);
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, tb, smem_a + blk * 32 * ROWB);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u)) s[kt][qt][e] = -INFINITY;
+            online_block<E, QT, true>(w, s, c, tb, vbase0 + blk * 32 * ROWB, pmax_unused);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float lt = wave_xor_sum_16_32(w.l[qt]);
+            scale_o[qt] = lt > 0.f ? 1.0f / lt : 0.f;                                   // acc * (1/l)   (triton_tree_attn.py:242)
+            lse_out[qt] = lt > 0.f ? w.m[qt] * p.scale + logf(lt) : -INFINITY;          // m*scale + ln(l) (:243)
+        }
+    } else {
+        // ---- LlamaAttention.tree_part_fwd numerics (llama.py:406-415): the QK^T result is rounded to the
+        // activation dtype, scaled before (last layer, G1) or after the product, soft-max in fp32, probabilities
+        // rounded before P.V (G2).  Three sweeps over the (tiny) block: row max, row sum, then P.V.
+        float tmax[QT], tsum[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            tmax[qt] = -INFINITY;
+            tsum[qt] = 0.f;
+        }
+        auto scores = [&](int blk, int qt, const f32x4 (&s)[2][QT], float (&sv)[8]) {
+            const uint32_t bits = mask_word(qt, blk);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float xs = round_to<E>(s[kt][qt][e]);
+                    if (!p.prescale_q) xs = round_to<E>(xs * p.scale);
+                    sv[kt * 4 + e] = ((bits >> (kt * 16 + g4 * 4 + e)) & 1u) ? xs : -INFINITY;
                 }
-                f32x4 s[2][QT];
-                qk_block<E, QT, QLDS>(s, qf, tb, qbase, smem_a + krow0 * ROWB);
-                if (p.new_mode != LS_NEW_TARGET) {
+        };
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; ++blk) {                     // sweep 0: row max
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, tb, smem_a + blk * 32 * ROWB);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt) {
+                float sv[8];
+                scores(blk, qt, s, sv);
+                float mx = sv[0];
 #pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (!((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u)) s[kt][qt][e] = -INFINITY;
-                    online_block<E, QT, true>(w, s, c, tb, smem_a + (TILE + krow0) * ROWB, pmax_unused);
-                    continue;
-                }
-                // ---- LlamaAttention.tree_part_fwd numerics (llama.py:406-415): the QK^T result is
-                // rounded to the activation dtype, scaled before (last layer, G1) or after the
-                // product, soft-max in fp32, probabilities rounded before P.V (G2).  Three passes
-                // over the (tiny) block: row max, row sum, then P.V.
-                typename E::V8 pf[QT];
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    float sv[8];
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = round_to<E>(s[kt][qt][e]);
-                            if (!p.prescale_q) x = round_to<E>(x * p.scale);
-                            sv[kt * 4 + e] = ((bits[qt] >> (kt * 16 + g4 * 4 + e)) & 1u) ? x : -INFINITY;
-                        }
-                    if (pass == 0) {
-                        float mx = sv[0];
-#pragma unroll
-                        for (int e = 1; e < 8; ++e) mx = fmaxf(mx, sv[e]);
-                        tmax[qt] = fmaxf(tmax[qt], wave_xor_max_16_32(mx));
-                    } else {
-                        const float mref = tmax[qt] == -INFINITY ? 0.f : tmax[qt];
-                        float ps = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            sv[e] = expf(sv[e] - mref);
-                            ps += sv[e];
-                        }
-                        if (pass == 1) {
-                            tsum[qt] += ps;
-                        } else {
-                            const float den = tsum[qt] > 0.f ? tsum[qt] : 1.f;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) pf[qt][e] = E::from_f32(sv[e] / den);
-                        }
-                    }
-                }
-                if (pass == 2) pv_block<E, QT>(w, pf, tb, smem_a + (TILE + krow0) * ROWB);
+                for (int e = 1; e < 8; ++e) mx = fmaxf(mx, sv[e]);
+                tmax[qt] = fmaxf(tmax[qt], wave_xor_max_16_32(mx));
             }
         }
-        if (p.new_mode == LS_NEW_TARGET && pass == 1) {
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; ++blk) {                     // sweep 1: row sum of exp(s - max)
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, tb, smem_a + blk * 32 * ROWB);
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) tsum[qt] = wave_xor_sum_16_32(tsum[qt]);
+            for (int qt = 0; qt < QT; ++qt) {
+                float sv[8];
+                scores(blk, qt, s, sv);
+                const float mref = tmax[qt] == -INFINITY ? 0.f : tmax[qt];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tsum[qt] += expf(sv[e] - mref);
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) tsum[qt] = wave_xor_sum_16_32(tsum[qt]);
+        acc_init<E, QT>(w);
+#pragma unroll 1
+        for (int blk = 0; blk < nblk; ++blk) {                     // sweep 2: P = dtype(exp(s - max) / sum), P.V
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, tb, smem_a + blk * 32 * ROWB);
+            typename E::V8 pf[QT];
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float sv[8];
+                scores(blk, qt, s, sv);
+                const float mref = tmax[qt] == -INFINITY ? 0.f : tmax[qt];
+                const float den = tsum[qt] > 0.f ? tsum[qt] : 1.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[qt][e] = E::from_f32(expf(sv[e] - mref) / den);
+            }
+            pv_block<E, QT>(w, pf, tb, vbase0 + blk * 32 * ROWB);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            scale_o[qt] = 1.f;
+            lse_out[qt] = tsum[qt] > 0.f ? tmax[qt] + logf(tsum[qt]) : -INFINITY;      // logsumexp (llama.py:415)
         }
     }
-    if (!worker) return;
 
+    constexpr bool round_o = MODE != LS_NEW_FLASH;     // fp16 matmul result (llama.py:414) / o stored in fp16 (triton :248)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float scale_o, lse;
-        bool round_o;
-        if (p.new_mode == LS_NEW_TARGET) {
-            scale_o = 1.f;
-            round_o = true;                                                        // fp16 matmul result (llama.py:414)
-            lse = tsum[qt] > 0.f ? tmax[qt] + logf(tsum[qt]) : -INFINITY;        // logsumexp (llama.py:415)
-        } else {
-            const float lt = wave_xor_sum_16_32(w.l[qt]);
-            scale_o = lt > 0.f ? 1.0f / lt : 0.f;              // acc * (1/l)   (triton_tree_attn.py:242)
-            round_o = p.new_mode == LS_NEW_DRAFT;              // o stored in fp16 (triton_tree_attn.py:248)
-            lse = lt > 0.f ? w.m[qt] * p.scale + logf(lt) : -INFINITY;            // m*scale + ln(l) (:243)
-        }
         const int m = row0 + qt * 16 + l15;
         if (m < p.M) {
             const int head = kvh * p.g + m / p.sq;
             float* op = p.new_o + (((long)bi * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                f32x4 o = w.acc[dt][qt] * scale_o;
+                f32x4 o = w.acc[dt][qt] * scale_o[qt];
                 if (round_o) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = round_to<E>(o[e]);
                 }
                 *reinterpret_cast<f32x4*>(op + dt * 16) = o;
             }
-            if (g4 == 0) p.new_lse[((long)bi * p.H + head) * p.sq + rrow[qt]] = lse;
+            if (g4 == 0) p.new_lse[((long)bi * p.H + head) * p.sq + rrow[qt]] = lse_out[qt];
         }
     }
 }
 
-template <typename E, int RB, int KS, int QT, int TKW>
-__global__ __launch_bounds__(256, 1) void attn_partial_kernel(const AttnK p) {
-    static_assert(RB * KS == 4, "4 waves per workgroup");
+template <typename E, int QT>
+__global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.has_new && blockIdx.x == 0)
-        new_block_path<E, RB, KS, QT, TKW>(p, smem);
-    else
-        prefix_path<E, RB, KS, QT, TKW>(p, smem, (int)blockIdx.x - p.has_new);
+    if (p.has_new && blockIdx.x == 0) {
+        KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (p.new_mode == LS_NEW_TARGET) new_block_path<E, QT, LS_NEW_TARGET>(pk, smem);
+        else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, QT, LS_NEW_DRAFT>(pk, smem);
+        else new_block_path<E, QT, LS_NEW_FLASH>(pk, smem);
+    } else {
+        prefix_path<E, QT>(p, smem, (int)blockIdx.x - p.has_new);
+    }
 }
 
 // ---- stage 2: combine + merge ----------------------------------------------------------
@@ -646,18 +680,36 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     const long part_o_stride = p.part_o_stride;
     const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
 
+    // pass 1: reference max over the parts (independent scalar loads)
     float mx = -INFINITY;
+#pragma unroll 8
     for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, p.parts_lse[i * part_lse_stride + lse_idx]);
     float lnew = -INFINITY;
     if (p.new_o != nullptr) lnew = p.new_lse[lse_idx];
     if (joint) mx = fmaxf(mx, lnew);
     const float mref = mx == -INFINITY ? 0.f : mx;
+    // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
+    // o = 0) so that 4 independent 16-byte loads are in flight per thread
     float den = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < p.n_parts; ++i) {
-        const float l = p.parts_lse[i * part_lse_stride + lse_idx];
-        if (l == -INFINITY) continue;
-        const float wgt = expf(l - mref);
+    int i = 0;
+    for (; i + 4 <= p.n_parts; i += 4) {
+        float l4[4];
+        f32x4 o4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            l4[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
+            o4[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wgt = expf(l4[u] - mref);
+            den += wgt;
+            o += o4[u] * wgt;
+        }
+    }
+    for (; i < p.n_parts; ++i) {
+        const float wgt = expf(p.parts_lse[i * part_lse_stride + lse_idx] - mref);
         den += wgt;
         o += *reinterpret_cast<const f32x4*>(p.parts_o + i * part_o_stride + o_idx) * wgt;
     }
@@ -724,24 +776,31 @@ __global__ void pack_mask_kernel(const int64_t* mask, int M, int N, uint32_t* bi
 
 // ---- host side ---------------------------------------------------------------------------
 struct Cfg {
-    int RB, KS, QT, TKW, row_chunks, rows_per_chunk;
+    int QT, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
 };
 
+// Workgroup shape for M = g*sq rows sharing one K/V stream (see the header comment).
 Cfg pick_cfg(int M) {
     Cfg c;
+    c.QT = M <= 16 ? 1 : 2;
+    const int rows_per_wave = c.QT * 16;
+    int rb = (M + rows_per_wave - 1) / rows_per_wave;
     c.row_chunks = 1;
-    if (M <= 80) {
-        c = Cfg{1, 4, (M + 15) / 16, 32, 1, 0};
-    } else if (M <= 160) {
-        c = Cfg{2, 2, 5, 32, 1, 0};
-    } else if (M <= 320) {
-        c = Cfg{4, 1, 5, 64, 1, 0};
-    } else if (M <= 384) {
-        c = Cfg{4, 1, 6, 32, 1, 0};      // 32-key tiles: 96 KB of Q image + 32 KB of K/V buffers
-    } else {
-        c = Cfg{4, 1, 5, 64, (M + 319) / 320, 0};
+    if (rb > 12) {                      // g*sq > 384 rows: several row chunks re-read the K/V stream
+        c.row_chunks = (M + 319) / 320;
+        rb = 10;
     }
-    c.rows_per_chunk = c.RB * c.QT * 16;
+    c.RB = rb;
+    c.KS = rb <= 3 ? 4 : (rb <= 6 ? 2 : 1);
+    c.bpw = c.KS == 1 ? 2 : 1;          // 32-key blocks per wave and tile
+    c.tile = c.KS * c.bpw * 32;         // 64 keys (KS = 1, 2) or 128 keys (KS = 4)
+    c.nstages = c.tile == 64 ? 4 : 2;   // 128 KB of LDS ring: 96 KB / 64 KB of K/V in flight per CU
+    const int nw = c.RB * c.KS;
+    c.nd = nw >= 8 ? 8 : (nw >= 4 ? 4 : (nw >= 2 ? 2 : 1));
+    c.pp = (c.tile / 2) / c.nd;         // pieces (1 KB) per DMA wave and tile
+    c.rows_per_chunk = c.RB * rows_per_wave;
+    c.threads = nw * 64;
+    c.lds = c.nstages * 2 * c.tile * ROWB + 16;
     return c;
 }
 
@@ -759,13 +818,15 @@ int num_cus() {
 
 int pick_splits(const ls_attn_desc* d, const Cfg& c) {
     if (d->n_splits > 0) return d->n_splits;
-    const int tile = c.KS * c.TKW;
+    const int tile = c.tile;
     int span = d->kv_len_hint;
     if (d->window_left >= 0) span = span < d->window_left + d->sq + 1 ? span : d->window_left + d->sq + 1;
     int tiles = (span + tile - 1) / tile + (d->window_left >= 0 ? 1 : 0);
     if (tiles < 1) tiles = 1;
     const int wg_per_split = d->Hkv * c.row_chunks * d->b;
-    int target = num_cus() / wg_per_split;
+    // one workgroup per CU in total: the new-block workgroups (one per kv head) count too, otherwise the
+    // surplus prefix workgroups start only when a CU frees up and the launch takes two rounds
+    int target = num_cus() / wg_per_split - (d->new_mode != LS_NEW_NONE ? 1 : 0);
     if (target < 1) target = 1;
     int s = target < tiles ? target : tiles;
     if (s > 512) s = 512;
@@ -807,6 +868,7 @@ int validate(const ls_attn_desc* d) {
             LS_FAIL(LS_ERR_INVALID_ARG, "new block: n_new=%d cached=%d mask_words=%d", d->n_new, d->n_new_cached, d->mask_words);
         if (d->n_new_cached < d->n_new && (!d->k_new || !d->v_new)) LS_FAIL(LS_ERR_INVALID_ARG, "k_new/v_new missing");
     }
+    if (d->new_mode != LS_NEW_NONE && d->n_new > 256) LS_FAIL(LS_ERR_UNSUPPORTED, "new block of %d keys > 256", d->n_new);
     if (!d->q || !d->k_cache || !d->v_cache || !d->cache_seqlens) LS_FAIL(LS_ERR_INVALID_ARG, "null tensor");
     if (d->kv_len_hint < 0) LS_FAIL(LS_ERR_INVALID_ARG, "kv_len_hint < 0");
     if ((d->q_stride_s | d->q_stride_h | d->kc_stride_s | d->kc_stride_h) & 7)
@@ -814,41 +876,22 @@ int validate(const ls_attn_desc* d) {
     return LS_OK;
 }
 
-template <typename E, int RB, int KS, int QT, int TKW>
-int launch_partial(const AttnK& k, dim3 grid, hipStream_t s) {
-    constexpr int TILE = KS * TKW;
-    const int lds = 2 * (2 * TILE * ROWB)                 // double-buffered (K,V) tiles
-                    + (QT >= 5 ? RB * QT * 16 * ROWB : 0)   // Q image of each row block
-                    + 16;                                   // redo flag
-    auto fn = attn_partial_kernel<E, RB, KS, QT, TKW>;
+template <typename E, int QT>
+int launch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+    auto fn = attn_partial_kernel<E, QT>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
+    hipLaunchKernelGGL(fn, grid, dim3(c.threads), c.lds, s, k);
     LS_CHECK_LAUNCH("attn_partial_kernel");
     return LS_OK;
 }
 
 template <typename E>
 int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    if (c.RB == 1 && c.KS == 4) {
-        switch (c.QT) {
-            case 1: return launch_partial<E, 1, 4, 1, 32>(k, grid, s);
-            case 2: return launch_partial<E, 1, 4, 2, 32>(k, grid, s);
-            case 3: return launch_partial<E, 1, 4, 3, 32>(k, grid, s);
-            case 4: return launch_partial<E, 1, 4, 4, 32>(k, grid, s);
-            case 5: return launch_partial<E, 1, 4, 5, 32>(k, grid, s);
-        }
-    } else if (c.RB == 2 && c.KS == 2 && c.QT == 5) {
-        return launch_partial<E, 2, 2, 5, 32>(k, grid, s);
-    } else if (c.RB == 4 && c.KS == 1 && c.QT == 5) {
-        return launch_partial<E, 4, 1, 5, 64>(k, grid, s);
-    } else if (c.RB == 4 && c.KS == 1 && c.QT == 6) {
-        return launch_partial<E, 4, 1, 6, 32>(k, grid, s);
-    }
-    LS_FAIL(LS_ERR_UNSUPPORTED, "no kernel for RB=%d KS=%d QT=%d", c.RB, c.KS, c.QT);
+    return c.QT == 1 ? launch_partial<E, 1>(c, k, grid, s) : launch_partial<E, 2>(c, k, grid, s);
 }
 
 int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s, WsLayout* out_layout) {
@@ -888,6 +931,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.n_splits = n_splits;
     k.row_chunks = c.row_chunks;
     k.rows_per_chunk = c.rows_per_chunk;
+    k.RB = c.RB; k.KS = c.KS; k.tile = c.tile; k.bpw = c.bpw; k.nstages = c.nstages; k.nd = c.nd; k.pp = c.pp;
     k.scale = d->softmax_scale;
     k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
