@@ -15,10 +15,11 @@
 // MI355X mapping.  All g = H/Hkv query heads of a kv head and all sq query rows are
 // packed into one M = g*sq row block that shares every K/V byte read from HBM (GQA-4,
 // 74 rows: 296 flop per KV byte, i.e. right at the MFMA/HBM ridge).  A workgroup is
-// RB x KS waves: RB row blocks of QT*16 rows (QT = 2: 32 rows per wave, 10 waves for the 296
-// rows of a Llama-3 verify pass) times KS key slices (small row counts).  2-3 waves share a
-// SIMD, so LDS, MFMA and VALU latencies of one wave are covered by the others.  Per 32-key
-// block a wave computes
+// RB x KS waves (<= 8: two per SIMD, 256 registers each): RB row blocks times KS key slices (small
+// row counts).  A row block is QT tiles of 16 rows; the 296 rows (19 tiles -> 20) of a Llama-3
+// verify pass are dealt 3,3,3,3,2,2,2,2 so that every SIMD (waves w and w+4) carries 5 tiles --
+// balanced matrix work, and the second wave of a SIMD covers the LDS / MFMA / VALU latencies of
+// the first.  Per 32-key block a wave computes
 //     S^T[key][row] = K . Q^T          (mfma_f32_16x16x32: A = K fragment,  B = Q^T fragment)
 //     O^T[d][row]  += V^T . P^T        (A = V^T via ds_read_b64_tr_b16,     B = P^T = S^T's own layout)
 // Both products are "transposed" so that a lane always owns ONE query row (lane&15):
@@ -42,7 +43,7 @@ namespace {
 constexpr int D = LS_HEAD_DIM;      // 128
 constexpr int ROWB = D * 2;         // bytes per key row (fp16/bf16)
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int MAX_THREADS = 768;    // up to 12 waves per workgroup
+constexpr int MAX_THREADS = 512;    // up to 8 waves per workgroup: 2 per SIMD, 256 registers each
 
 struct AttnK {
     const void* q;
@@ -65,6 +66,8 @@ struct AttnK {
     // workgroup shape (host-chosen): RB row blocks x KS key slices waves; a tile = `tile` keys
     // (KS * bpw * 32), `nstages` tiles of LDS ring, DMA by the first `nd` waves, `pp` pieces each
     int RB, KS, tile, bpw, nstages, nd, pp;
+    // row blocks 0..rbA-1 have qtA tiles of 16 rows, the others qtB
+    int rbA, qtA, qtB;
     float scale;
     long q_sb, q_ss, q_sh;
     long kc_sb, kc_ss, kc_sh;
@@ -204,12 +207,35 @@ __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)
             for (int e = 0; e < 4; ++e) {
                 const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
                 ps += pe;
-                if (!SAFE) pmax = fmaxf(pmax, pe);
                 pf[qt][kt * 4 + e] = E::from_f32(pe);
             }
         w.l[qt] += ps;
+        if (!SAFE) pmax = fmaxf(pmax, ps);   // sum of 8 probabilities: a conservative stand-in for their max
     }
     pv_block<E, QT>(w, pf, tb, vbase);
+}
+
+// Fixed-reference soft-max of one 32-key block (SAFE = false form of online_block) WITHOUT the P.V
+// product: returns the probabilities as the B operand of the next P.V so that the caller can issue
+// them under the MFMAs of the previous block's P.V (software pipeline of the interior loop).
+template <typename E, int QT>
+__device__ __forceinline__ void softmax_fast(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], float c, typename E::V8 (&pf)[QT],
+                                             float& pmax) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float mc = w.m[qt] * c;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                ps += pe;
+                pf[qt][kt * 4 + e] = E::from_f32(pe);
+            }
+        w.l[qt] += ps;
+        pmax = fmaxf(pmax, ps);        // sum of 8 probabilities: a conservative stand-in for their max
+    }
 }
 
 // ---- HBM -> LDS tile DMA -----------------------------------------------------------------
@@ -273,7 +299,7 @@ __device__ __forceinline__ void ctx_init(Ctx<E, QT>& x, const AttnK& p, char* sm
     x.c = p.scale * LOG2E;
     x.sk = x.L + p.n_app;
     // rows of this wave: lane l15 of q-tile qt owns row m = row0 + qt*16 + l15
-    x.row0 = x.chunk * p.rows_per_chunk + x.rb * QT * 16;
+    x.row0 = x.chunk * p.rows_per_chunk + (x.rb < p.rbA ? x.rb * p.qtA : p.rbA * p.qtA + (x.rb - p.rbA) * p.qtB) * 16;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int m = x.row0 + qt * 16 + x.l15;
@@ -366,23 +392,28 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
     // attempt 1 (only if some p came close to the fp16 range): textbook form everywhere.
     int* redo_flag = reinterpret_cast<int*>(smem + S * STAGE);
     float pmax = 0.f;
-    auto run_tiles = [&](int t_from, int t_to, auto safe_tag) {
-        constexpr bool SAFE = decltype(safe_tag)::value;
+    // DMA schedule: LA = max(S-2, 1) tiles ahead.  One ring slot stays untouched behind the tile being
+    // multiplied because the interior loop defers the P.V of a tile's last block into the next iteration.
+    const int LA = S > 2 ? S - 2 : 1;
+    auto tile_head = [&](int t) -> unsigned {
+        // tile t landed once at most the pieces of the younger tiles in flight are outstanding
+        const int younger = min(LA - 1, t_end - 1 - t);
+        wait_vmcnt(dma_wave ? younger * p.pp : 0);
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of tile t landed; iteration t-1 is over everywhere
+        if (t + LA < t_end) dma(t + LA);
+        return x.smem_a + ((t - t_begin) % S) * STAGE;      // K tile; V tile follows at + TILE*ROWB
+    };
+    auto run_safe = [&](int t_from, int t_to) {
         for (int t = t_from; t < t_to; ++t) {
-            // tile t landed once at most the pieces of the younger tiles in flight are outstanding
-            const int younger = min(S - 2, t_end - 1 - t);
-            wait_vmcnt(dma_wave ? younger * p.pp : 0);
-            __builtin_amdgcn_s_barrier();          // every wave's pieces of tile t landed; tile t-1 fully consumed
-            if (t + S - 1 < t_end) dma(t + S - 1);  // refill the slot tile t-1 just vacated
-            const unsigned kb_a = x.smem_a + ((t - t_begin) % S) * STAGE;      // K tile; V tile follows at + TILE*ROWB
+            const unsigned kb_a = tile_head(t);
 #pragma unroll 1
             for (int blk = 0; blk < p.bpw; ++blk) {
                 const int krow0 = (x.ks * p.bpw + blk) * 32;
                 const int ka0 = t * TILE + krow0;
-                if (SAFE && (ka0 >= hi_max || ka0 + 32 <= lo_min)) continue;   // wave-uniform
+                if (ka0 >= hi_max || ka0 + 32 <= lo_min) continue;   // wave-uniform
                 f32x4 s[2][QT];
                 qk_block<E, QT>(s, qf, x.tb, kb_a + krow0 * ROWB);
-                if (SAFE && !(ka0 >= lo_max && ka0 + 32 <= hi_min)) {          // block touches a range edge
+                if (!(ka0 >= lo_max && ka0 + 32 <= hi_min)) {        // block touches a range edge
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const int lo = p.window_left >= 0 ? max(0, x.rrow[qt] + sk - p.sq - p.window_left) : 0;
@@ -396,24 +427,75 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
                             }
                     }
                 }
-                online_block<E, QT, SAFE>(w, s, x.c, x.tb, kb_a + (TILE + krow0) * ROWB, pmax);
+                online_block<E, QT, true>(w, s, x.c, x.tb, kb_a + (TILE + krow0) * ROWB, pmax);
             }
         }
+    };
+    // Interior tiles, software-pipelined over 32-key blocks:  QK^T(b) ; { P.V(b-1)  ||  exp2(b) }.
+    // The P.V MFMAs of the previous block and the soft-max VALU work of the current one are independent,
+    // so each wave always has matrix and vector work to issue.
+    auto run_fast = [&](int t_from, int t_to) {
+        if (t_from >= t_to) return;
+        if (QT > 2) {
+            // 3-tile row blocks (96 accumulator + 48 Q registers) have no room for a second set of
+            // probabilities: same schedule without the deferral (their SIMD partner is a 2-tile wave
+            // that runs the pipelined form, so matrix and vector phases still interleave on the SIMD)
+            for (int t = t_from; t < t_to; ++t) {
+                const unsigned kb_a = tile_head(t);
+#pragma unroll 1
+                for (int blk = 0; blk < p.bpw; ++blk) {
+                    const int krow0 = (x.ks * p.bpw + blk) * 32;
+                    f32x4 s[2][QT];
+                    qk_block<E, QT>(s, qf, x.tb, kb_a + krow0 * ROWB);
+                    online_block<E, QT, false>(w, s, x.c, x.tb, kb_a + (TILE + krow0) * ROWB, pmax);
+                }
+            }
+            return;
+        }
+        typename E::V8 pf_prev[QT];
+        int t = t_from, blk = 0;
+        unsigned kb_a = tile_head(t);
+        unsigned v_prev;
+        {   // pipeline fill: first block
+            const int krow0 = (x.ks * p.bpw) * 32;
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, x.tb, kb_a + krow0 * ROWB);
+            softmax_fast<E, QT>(w, s, x.c, pf_prev, pmax);
+            v_prev = kb_a + (TILE + krow0) * ROWB;
+        }
+        while (true) {
+            if (++blk == p.bpw) {
+                blk = 0;
+                if (++t == t_to) break;
+                kb_a = tile_head(t);
+            }
+            const int krow0 = (x.ks * p.bpw + blk) * 32;
+            f32x4 s[2][QT];
+            qk_block<E, QT>(s, qf, x.tb, kb_a + krow0 * ROWB);
+            typename E::V8 pf[QT];
+            pv_block<E, QT>(w, pf_prev, x.tb, v_prev);          // MFMA: previous block
+            softmax_fast<E, QT>(w, s, x.c, pf, pmax);          // VALU: this block (independent of the P.V above)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) pf_prev[qt] = pf[qt];
+            v_prev = kb_a + (TILE + krow0) * ROWB;
+        }
+        pv_block<E, QT>(w, pf_prev, x.tb, v_prev);      // drain (the slot of tile t_to-1 is still intact)
     };
     for (int attempt = 0; attempt < 2; ++attempt) {
         acc_init<E, QT>(w);
         pmax = 0.f;
         if (x.tid == 0) *redo_flag = 0;
-        for (int i = 0; i < S - 1 && t_begin + i < t_end; ++i) dma(t_begin + i);      // S-1 tiles in flight
+        for (int i = 0; i < LA && t_begin + i < t_end; ++i) dma(t_begin + i);      // LA tiles in flight
         // interior tiles: whole tile inside [lo_max, hi_min); the first tile always primes the max
         int tA = max(t_begin + 1, (lo_max + TILE - 1) / TILE);
         int tB = min(t_end, hi_min / TILE);
         if (attempt == 1 || tB < tA) tA = tB = t_end;
-        run_tiles(t_begin, tA, std::true_type{});
-        run_tiles(tA, tB, std::false_type{});
-        run_tiles(tB, t_end, std::true_type{});
+        run_safe(t_begin, tA);
+        run_fast(tA, tB);
+        run_safe(tB, t_end);
         if (attempt == 1) break;
-        if (__any(pmax > 16384.f) && x.lane == 0) *redo_flag = 1;     // 2^14: two octaves below fp16 max
+        // fp16 tops out at 65504: a block sum of 2^14 is two octaves below it
+        if (__any(pmax > 16384.f) && x.lane == 0) *redo_flag = 1;
         __syncthreads();
         const int redo = *redo_flag;
         __syncthreads();
@@ -639,8 +721,7 @@ __device__ __attribute__((noinline)) void new_block_path(KernArgAttnK* pk, char*
 }
 
 template <typename E, int QT>
-__global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
     if (p.has_new && blockIdx.x == 0) {
         KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
         if (p.new_mode == LS_NEW_TARGET) new_block_path<E, QT, LS_NEW_TARGET>(pk, smem);
@@ -648,6 +729,20 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p
         else new_block_path<E, QT, LS_NEW_FLASH>(pk, smem);
     } else {
         prefix_path<E, QT>(p, smem, (int)blockIdx.x - p.has_new);
+    }
+}
+
+// Row blocks 0..rbA-1 carry QTA tiles, the rest QTB: both instantiations execute the same barrier
+// sequence (identical tile loop), so a workgroup may mix them wave by wave.
+template <typename E, int QTA, int QTB>
+__global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (QTA == QTB) {
+        partial_entry<E, QTA>(p, smem);
+    } else {
+        const int rb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / p.KS;
+        if (rb < p.rbA) partial_entry<E, QTA>(p, smem);
+        else partial_entry<E, QTB>(p, smem);
     }
 }
 
@@ -776,29 +871,31 @@ __global__ void pack_mask_kernel(const int64_t* mask, int M, int N, uint32_t* bi
 
 // ---- host side ---------------------------------------------------------------------------
 struct Cfg {
-    int QT, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
+    int qtA, qtB, rbA, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
 };
 
 // Workgroup shape for M = g*sq rows sharing one K/V stream (see the header comment).
 Cfg pick_cfg(int M) {
     Cfg c;
-    c.QT = M <= 16 ? 1 : 2;
-    const int rows_per_wave = c.QT * 16;
-    int rb = (M + rows_per_wave - 1) / rows_per_wave;
+    int tiles = (M + 15) / 16;
     c.row_chunks = 1;
-    if (rb > 12) {                      // g*sq > 384 rows: several row chunks re-read the K/V stream
+    if (tiles > 24) {                   // g*sq > 384 rows: several row chunks re-read the K/V stream
         c.row_chunks = (M + 319) / 320;
-        rb = 10;
+        tiles = 20;
     }
-    c.RB = rb;
-    c.KS = rb <= 3 ? 4 : (rb <= 6 ? 2 : 1);
+    if (tiles <= 1) { c.qtA = c.qtB = 1; c.RB = 1; c.KS = 2; }
+    else if (tiles <= 8) { c.qtA = c.qtB = 2; c.RB = (tiles + 1) / 2; c.KS = 2; }
+    else if (tiles <= 16) { c.qtA = c.qtB = 2; c.RB = (tiles + 1) / 2; c.KS = 1; }
+    else if (tiles <= 20) { c.qtA = 3; c.qtB = 2; c.RB = 8; c.KS = 1; }      // 3,3,3,3,2,2,2,2
+    else { c.qtA = c.qtB = 3; c.RB = 8; c.KS = 1; }
+    c.rbA = c.qtA == c.qtB ? c.RB : 4;
     c.bpw = c.KS == 1 ? 2 : 1;          // 32-key blocks per wave and tile
-    c.tile = c.KS * c.bpw * 32;         // 64 keys (KS = 1, 2) or 128 keys (KS = 4)
-    c.nstages = c.tile == 64 ? 4 : 2;   // 128 KB of LDS ring: 96 KB / 64 KB of K/V in flight per CU
+    c.tile = 64;
+    c.nstages = 4;                      // 128 KB LDS ring; 2 tiles (64 KB) in flight beside the 2 being read
     const int nw = c.RB * c.KS;
     c.nd = nw >= 8 ? 8 : (nw >= 4 ? 4 : (nw >= 2 ? 2 : 1));
     c.pp = (c.tile / 2) / c.nd;         // pieces (1 KB) per DMA wave and tile
-    c.rows_per_chunk = c.RB * rows_per_wave;
+    c.rows_per_chunk = (c.rbA * c.qtA + (c.RB - c.rbA) * c.qtB) * 16;
     c.threads = nw * 64;
     c.lds = c.nstages * 2 * c.tile * ROWB + 16;
     return c;
@@ -876,9 +973,9 @@ int validate(const ls_attn_desc* d) {
     return LS_OK;
 }
 
-template <typename E, int QT>
+template <typename E, int QTA, int QTB>
 int launch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    auto fn = attn_partial_kernel<E, QT>;
+    auto fn = attn_partial_kernel<E, QTA, QTB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -891,7 +988,10 @@ int launch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
 
 template <typename E>
 int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    return c.QT == 1 ? launch_partial<E, 1>(c, k, grid, s) : launch_partial<E, 2>(c, k, grid, s);
+    if (c.qtA == 1) return launch_partial<E, 1, 1>(c, k, grid, s);
+    if (c.qtA == 2) return launch_partial<E, 2, 2>(c, k, grid, s);
+    if (c.qtB == 2) return launch_partial<E, 3, 2>(c, k, grid, s);
+    return launch_partial<E, 3, 3>(c, k, grid, s);
 }
 
 int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s, WsLayout* out_layout) {
@@ -932,6 +1032,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.row_chunks = c.row_chunks;
     k.rows_per_chunk = c.rows_per_chunk;
     k.RB = c.RB; k.KS = c.KS; k.tile = c.tile; k.bpw = c.bpw; k.nstages = c.nstages; k.nd = c.nd; k.pp = c.pp;
+    k.rbA = c.rbA; k.qtA = c.qtA; k.qtB = c.qtB;
     k.scale = d->softmax_scale;
     k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
