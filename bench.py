@@ -203,7 +203,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pool = EventPool(cfg.num_hidden_layers * args.steps) if world == 1 else None
+    pool = EventPool(cfg.num_hidden_layers * args.steps) if rank == 0 else None
     if pool is not None:
         for layer in m.model.layers:
             layer.self_attn.timing = pool.next
@@ -244,6 +244,24 @@ def main():
         "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
     }
 
+    if rank == 0:
+        # ---- roofline of the dominant kernel (hybrid verification attention, stage 1; this rank's KV shard) ----
+        mean_us = pool.mean_us()
+        ab = algo_bytes_verify(Ls, H, Hkv)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = ab / (mean_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                           "kernel": "attn_partial_kernel (verification attention, stage 1)",
+                           "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
+                           "launches_timed": pool.i,
+                           "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
     if rank == 0 and world == 1:
         # ---- speed-up denominator: vanilla autoregressive decode on the same model and prefix ----------
         with torch.inference_mode():
@@ -263,23 +281,6 @@ def main():
             vanilla_tps = args.vanilla_steps / (time.time() - tv)
         out["vanilla_tokens_per_s"] = round(vanilla_tps, 3)
         out["speedup_vs_vanilla"] = round(value / vanilla_tps, 3)
-        # ---- roofline of the dominant kernel (hybrid verification attention, stage 1) ----------------
-        mean_us = pool.mean_us()
-        ab = algo_bytes_verify(Ls, H, Hkv)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        achieved = ab / (mean_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                           "kernel": "attn_partial_kernel (verification attention, stage 1)",
-                           "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
-                           "launches_timed": pool.i,
-                           "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, Ls, args.cpu_sample_calls, tau)
     if rank == 0:

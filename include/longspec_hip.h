@@ -52,7 +52,8 @@ typedef struct ls_attn_desc {
     const int32_t* cache_seqlens; /* [b] valid prefix rows L (device)                             */
     const uint32_t* mask_bits;    /* [b, sq, mask_words] bit j of row r = new-block key j visible */
     void* out;          /* [b, sq, H, 128] dtype                out_stride_{b,s,h}                */
-    float* lse;         /* [b, H, sq] fp32 or NULL (LS_NEW_NONE / LS_NEW_FLASH only)              */
+    float* lse;         /* [b, H, sq] fp32 or NULL: soft-max log-normaliser (NONE/FLASH); the tree   */
+                        /* kernel's L in LS_NEW_DRAFT mode; not available in LS_NEW_TARGET mode     */
     void* ev_start;     /* optional hipEvent_t pair recorded on `stream` around the stage-1 kernel  */
     void* ev_stop;      /* (profiling: per-launch duration of the streaming kernel), or NULL        */
     /* dims */

@@ -130,10 +130,12 @@ __device__ __forceinline__ void qk_block(f32x4 (&s)[2][QT], const typename E::V8
         typename E::V8 kf[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) kf[kt] = lds_read16<typename E::V8>(ka + kt * 16 * ROWB);
+        __builtin_amdgcn_s_setprio(1);          // keep the matrix pipe fed while the SIMD partner issues LDS / VALU work
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[kt], qf[qt][k4], s[kt][qt]);
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -587,12 +589,23 @@ __device__ __attribute__((noinline)) void new_block_path(KernArgAttnK* pk, char*
         }
     });
     const bool worker = (x.ks == 0) && (x.rb < p.RB);   // the few new keys are not split across key slices
+    // mask words of this lane's rows (<= 8 words for <= 256 keys), fetched under the DMA latency
+    uint32_t mw[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = row0 + qt * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            mw[qt][j] = (m < p.M && j < nblk) ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + j] : 0u;
+    }
     __syncthreads();                                   // keys landed (vmcnt(0) + barrier)
     if (!worker) return;
     const unsigned vbase0 = smem_a + cap * ROWB;
     auto mask_word = [&](int qt, int blk) -> uint32_t {
-        const int m = row0 + qt * 16 + l15;
-        return m < p.M ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + blk] : 0u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r = (j == blk) ? mw[qt][j] : r;      // select without dynamic register indexing
+        return r;
     };
 
     WaveAcc<E, QT> w;
@@ -819,7 +832,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         lse = mref + logf(den);
     }
     if (p.o32) *reinterpret_cast<f32x4*>(p.o32 + o_idx) = o;
-    if (p.lse_out && (tid & 31) == 0) p.lse_out[lse_idx] = lse;
+    // LS_NEW_DRAFT: the log-normaliser asked for is the tree kernel's L (triton_tree_attn.attention returns (o, L))
+    if (p.lse_out && (tid & 31) == 0) p.lse_out[lse_idx] = (p.mode == LS_NEW_DRAFT) ? lnew : lse;
     if (!p.out) return;
 
     float res[4];
@@ -1096,8 +1110,7 @@ int ls_attn_fwd(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) 
     int rc = run_partial(d, ws, ws_bytes, static_cast<hipStream_t>(stream), &w);
     if (rc) return rc;
     if (!d->out) LS_FAIL(LS_ERR_INVALID_ARG, "out is null");
-    if (d->lse && d->new_mode != LS_NEW_NONE && d->new_mode != LS_NEW_FLASH)
-        LS_FAIL(LS_ERR_INVALID_ARG, "lse output only for LS_NEW_NONE/LS_NEW_FLASH");
+    if (d->lse && d->new_mode == LS_NEW_TARGET) LS_FAIL(LS_ERR_INVALID_ARG, "no lse output in LS_NEW_TARGET mode");
     char* base = static_cast<char*>(ws);
     const bool has_new = d->new_mode != LS_NEW_NONE;
     return run_finish(d, reinterpret_cast<float*>(base + w.parts_o), reinterpret_cast<float*>(base + w.parts_lse),

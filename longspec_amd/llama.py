@@ -71,7 +71,12 @@ class LlamaRMSNorm(nn.Module):
         self.variance_epsilon = eps
         self.ops = ops
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, residual=None):
+        """``residual`` given: returns (norm(residual + hidden_states), residual + hidden_states) from one
+        kernel -- the `hidden_states = residual + hidden_states` of the decoder layers (``llama.py:492``)
+        fused into the norm that follows it (same fp16 rounding of the sum)."""
+        if residual is not None:
+            return self.ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon, residual=residual)
         return self.ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
 
 
@@ -169,9 +174,10 @@ class LlamaAttention(nn.Module):
                 tree_mask_bits = self.ops.pack_tree_mask(tree_mask)
             if self.shard is not None:
                 sh = self.shard
+                extra = {"timing": self.timing()} if self.timing is not None else {}
                 call = self.ops.sharded_verify_attention(q, k, v, self.K_Cache, self.V_Cache, sh.local_len(cache_lens),
                                                          tree_mask_bits, self.last_layer, softmax_scale=self.softmax_scale,
-                                                         kv_len_hint=sh.local_hint(self.kv_len_hint))
+                                                         kv_len_hint=sh.local_hint(self.kv_len_hint), **extra)
                 attn = sh.attend(call)
                 return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
             extra = {"timing": self.timing()} if self.timing is not None else {}
@@ -197,9 +203,7 @@ class LlamaDecoderLayer(nn.Module):
         hidden_states, kv_cache = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                                  cache_lens=cache_lens, exec_type=exec_type, tree_mask=tree_mask,
                                                  tree_mask_bits=tree_mask_bits)
-        hidden_states = residual + hidden_states
-        residual = hidden_states
-        hidden_states = self.post_attention_layernorm(hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual=residual)   # residual + attn, then norm
         hidden_states = self.mlp(hidden_states)
         hidden_states = residual + hidden_states
         return hidden_states, kv_cache

@@ -153,15 +153,11 @@ class LlamaGlideDecoderLayer(nn.Module):
         hidden_states = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                        cache_lens=cache_lens, exec_type="sa_" + exec_type, tree_mask=tree_mask,
                                        tree_mask_bits=bits)
-        hidden_states = residual + hidden_states
-        residual = hidden_states
-        hidden_states = self.post_self_attention_layernorm(hidden_states)
+        hidden_states, residual = self.post_self_attention_layernorm(hidden_states, residual=residual)   # + residual, norm
         hidden_states = self.cross_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                         cache_lens=cache_lens, exec_type="ca_" + exec_type, k_cache=llm_kv[0],
                                         v_cache=llm_kv[1], llm_kv_len=llm_kv_len, tree_mask=tree_mask, tree_mask_bits=bits)
-        hidden_states = hidden_states + residual
-        residual = hidden_states
-        hidden_states = self.post_cross_attention_layernorm(hidden_states)
+        hidden_states, residual = self.post_cross_attention_layernorm(hidden_states, residual=residual)  # + residual, norm
         hidden_states = self.mlp(hidden_states)
         hidden_states = hidden_states + residual
         return hidden_states

@@ -249,6 +249,27 @@ def draft_tree_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bit
     return out
 
 
+def tree_attention(q, k, v, tree_mask, sm_scale=None):
+    """``triton_tree_attn.attention(q, k, v, tree_mask)`` (``longspec/test/triton_tree_attn.py:19-77``):
+    q [B,H,M,128], k/v [B,Hkv,N,128], tree_mask [B,M,N] (non-zero = visible) -> (o [B,H,M,128], L [B,H,M] fp32).
+    Runs the draft-mode new-block path over an empty prefix."""
+    _dev(q, k, v, tree_mask)
+    B, H, M, D = q.shape
+    Hkv, N = k.shape[1], k.shape[2]
+    qt = q.permute(0, 2, 1, 3).contiguous()
+    kt = k.permute(0, 2, 1, 3).contiguous()
+    vt = v.permute(0, 2, 1, 3).contiguous()
+    out = torch.empty((B, M, H, D), dtype=q.dtype, device=q.device)
+    L = torch.empty((B, H, M), dtype=torch.float32, device=q.device)
+    zeros = torch.zeros((B,), dtype=torch.int32, device=q.device)
+    bits = pack_tree_mask(tree_mask)
+    # the keys double as an (unread) one-row-per-key "cache": cache_seqlens = 0 makes the prefix empty
+    d = _desc(qt, kt, vt, zeros, 0, k_new=kt, v_new=vt, mask_bits=bits, out=out, lse=L, new_mode=LS_NEW_DRAFT, n_new=N,
+              softmax_scale=sm_scale)
+    _run(d, q.device)
+    return out.permute(0, 2, 1, 3), L
+
+
 def lse_merge(parts_o: torch.Tensor, parts_lse: torch.Tensor, dtype=None, want_o32=False):
     """parts_o [W,b,sq,H,128] fp32, parts_lse [W,b,H,sq] fp32 -> merged out (dtype) and/or (o32, lse)."""
     _dev(parts_o, parts_lse)
@@ -310,7 +331,7 @@ class ShardedAttnCall:
 
 
 def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits, last_layer,
-                             softmax_scale=1.0 / (128 ** 0.5), kv_len_hint=None) -> ShardedAttnCall:
+                             softmax_scale=1.0 / (128 ** 0.5), kv_len_hint=None, timing=None) -> ShardedAttnCall:
     """Like ``verify_attention`` but ``k_cache/v_cache`` hold only this rank's prefix rows
     (``local_lens`` valid rows); the new rows are scattered at ``local_lens`` of the LOCAL cache
     (only the tail-owning rank's copy is ever read back as prefix)."""
@@ -320,7 +341,7 @@ def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask
     out = torch.empty((b, R, H, D), dtype=q.dtype, device=q.device)
     d = _desc(q, k_cache, v_cache, local_lens, _hint(local_lens, kv_len_hint, k_cache), k_new=k_new, v_new=v_new,
               mask_bits=mask_bits, out=out, new_mode=LS_NEW_TARGET, n_new=R, scatter_new=1, prescale_q=last_layer,
-              softmax_scale=softmax_scale)
+              softmax_scale=softmax_scale, timing=timing)
     return ShardedAttnCall(d, out, q.device)
 
 

@@ -112,7 +112,7 @@ class _ShardCall:
 
 
 def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask_bits, last_layer,
-                             softmax_scale=1 / (128 ** 0.5), kv_len_hint=None):
+                             softmax_scale=1 / (128 ** 0.5), kv_len_hint=None, timing=None):
     return _ShardCall(q, k_cache, v_cache, local_lens, verify=(k_new, v_new, mask_bits, last_layer, softmax_scale))
 
 

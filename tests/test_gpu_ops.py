@@ -318,6 +318,15 @@ def test_draft_attention_chain_golden(ops, c):
         assert torch.equal(kc.cpu(), kc_o) and torch.equal(vc.cpu(), vc_o)
 
 
+@pytest.mark.parametrize("c", list(cases.triton_cases()), ids=lambda c: c["name"])
+def test_tree_attention_triton_golden(ops, c):
+    """G-a: the Triton tree kernel seam ``attention(q, k, v, tree_mask) -> (o, L)`` against the REAL Triton
+    kernel's outputs (interpreter run of the reference)."""
+    o, L = ops.tree_attention(g(c["q"]), g(c["k"]), g(c["v"]), g(c["mask"]))
+    assert_close_f16(o, c["o"], atol=1.1e-3, frac=0.05, what="tree o")
+    assert (L.cpu() - c["L"]).abs().max().item() <= 5e-6
+
+
 # --------------------------------------------------------------------------- #
 # BASELINE sizes: size-independent properties
 # --------------------------------------------------------------------------- #
