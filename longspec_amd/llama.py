@@ -101,6 +101,8 @@ def chunked_causal_prefill(ops, q, k, v, k_cache, v_cache, window_left=-1):
 class LlamaAttention(nn.Module):
     """``LlamaAttention`` (``longspec/test/llama.py:55-421``): prefill / decoding / tree_decoding."""
 
+    QKV_BIAS = None      # None: config.attention_bias (Llama); True in the Qwen2 twin (qwen2.py:214-216)
+
     def __init__(self, config, layer_idx: int, ops=None):
         super().__init__()
         self.config = config
@@ -110,7 +112,7 @@ class LlamaAttention(nn.Module):
         self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.num_heads
         self.num_key_value_heads = config.num_key_value_heads
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
-        bias = getattr(config, "attention_bias", False)
+        bias = getattr(config, "attention_bias", False) if self.QKV_BIAS is None else self.QKV_BIAS
         self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
         self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
         self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
@@ -188,10 +190,12 @@ class LlamaAttention(nn.Module):
 
 
 class LlamaDecoderLayer(nn.Module):
+    ATTENTION_CLS = LlamaAttention
+
     def __init__(self, config, layer_idx: int, ops=None):
         super().__init__()
         self.hidden_size = config.hidden_size
-        self.self_attn = LlamaAttention(config, layer_idx, ops=ops)
+        self.self_attn = self.ATTENTION_CLS(config, layer_idx, ops=ops)
         self.mlp = LlamaMLP(config)
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
@@ -210,6 +214,8 @@ class LlamaDecoderLayer(nn.Module):
 
 
 class LlamaModel(nn.Module):
+    LAYER_CLS = LlamaDecoderLayer
+
     def __init__(self, config, ops=None):
         super().__init__()
         self.config = config
@@ -217,7 +223,7 @@ class LlamaModel(nn.Module):
         self.padding_idx = getattr(config, "pad_token_id", None)
         self.vocab_size = config.vocab_size
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
-        self.layers = nn.ModuleList([LlamaDecoderLayer(config, i, ops=ops) for i in range(config.num_hidden_layers)])
+        self.layers = nn.ModuleList([self.LAYER_CLS(config, i, ops=ops) for i in range(config.num_hidden_layers)])
         self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
         self.rotary_emb = LlamaRotaryEmbedding(config, ops=ops)
 
@@ -250,11 +256,13 @@ class LlamaModel(nn.Module):
 
 
 class LlamaForCausalLM(nn.Module):
+    MODEL_CLS = LlamaModel
+
     def __init__(self, config, ops=None):
         super().__init__()
         self.config = config
         self.ops = ops if ops is not None else _default_ops()
-        self.model = LlamaModel(config, ops=self.ops)
+        self.model = self.MODEL_CLS(config, ops=self.ops)
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
 

@@ -28,6 +28,7 @@ class GlideAttention(nn.Module):
     window of 512 over its own KV cache, and cross-attention over the target's last-layer KV."""
 
     WINDOW = 512
+    CACHE_PAD = 128      # extra draft-cache rows at prefill (llama_glide.py:218-219); 0 in the Qwen2 twin (qwen2_glide.py:217-218)
 
     def __init__(self, config, layer_idx: Optional[int] = None, ops=None):
         super().__init__()
@@ -94,8 +95,8 @@ class GlideAttention(nn.Module):
     def prefill(self, hidden_states, position_embeddings):                      # :206-233
         bsz, q_len, _ = hidden_states.size()
         q, k, v = self._qkv(hidden_states, position_embeddings)
-        self.K_Cache = q.new_zeros((bsz, q_len + self.max_len + 128, self.num_key_value_heads, self.head_dim))
-        self.V_Cache = q.new_zeros((bsz, q_len + self.max_len + 128, self.num_key_value_heads, self.head_dim))
+        self.K_Cache = q.new_zeros((bsz, q_len + self.max_len + self.CACHE_PAD, self.num_key_value_heads, self.head_dim))
+        self.V_Cache = q.new_zeros((bsz, q_len + self.max_len + self.CACHE_PAD, self.num_key_value_heads, self.head_dim))
         attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache, window_left=self.WINDOW)
         return self.o_proj(attn.reshape(bsz, q_len, self.hidden_size))
 
@@ -129,14 +130,16 @@ class LlamaGlideDecoderLayer(nn.Module):
     """``LlamaGlideDecoderLayer`` (``llama_glide.py:388-468``): norm -> self-attn -> +res ->
     norm -> cross-attn -> +res -> norm -> MLP -> +res; no final norm."""
 
+    ATTENTION_CLS = GlideAttention
+
     def __init__(self, config, ops=None):
         super().__init__()
         self.config = config
         self.ops = ops if ops is not None else _default_ops()
         self.hidden_size = config.hidden_size
         self.layer_idx = 0
-        self.self_attn = GlideAttention(config, self.layer_idx, ops=self.ops)
-        self.cross_attn = GlideAttention(config, self.layer_idx, ops=self.ops)
+        self.self_attn = self.ATTENTION_CLS(config, self.layer_idx, ops=self.ops)
+        self.cross_attn = self.ATTENTION_CLS(config, self.layer_idx, ops=self.ops)
         self.mlp = LlamaMLP(config)
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
         self.post_self_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
@@ -174,9 +177,11 @@ class LlamaGlide(LlamaForCausalLM):
     (safetensors / .bin) when paths are given; ``target_model_path=None`` builds random-init
     modules (tests, synthetic benchmarks)."""
 
+    GLIDE_LAYER_CLS = LlamaGlideDecoderLayer
+
     def __init__(self, config, target_model_path=None, glide_path=None, ops=None, dtype=torch.float16, device=None):
         super().__init__(config, ops=ops)
-        self.glide = LlamaGlideDecoderLayer(config, ops=self.ops)
+        self.glide = self.GLIDE_LAYER_CLS(config, ops=self.ops)
         if target_model_path is not None or glide_path is not None:
             from .checkpoint import load_draft_checkpoint, load_target_checkpoint
             if target_model_path is not None:
@@ -200,6 +205,15 @@ class LlamaGlide(LlamaForCausalLM):
         self.glide.self_attn.kv_len_hint = draft_bound
         self.glide.cross_attn.llm_kv_len_hint = target_bound
 
+    def _stop_id(self, eos_id, loop: str):
+        """Token whose appearance ends a loop.  The Llama twin tests ``self.config.eos_token_id`` in all
+        three loops (llama_glide.py:578,767,1120) and ignores the ``eos_id`` argument for that."""
+        return getattr(self.config, "eos_token_id", None)
+
+    def _tree_output_fill(self, eos_id):
+        """Initial content of ``output_ids`` in tree_spec_generate (llama_glide.py:937: eos_id, G8)."""
+        return eos_id
+
     def _last_kv(self):
         attn = self.model.layers[-1].self_attn
         return attn.K_Cache, attn.V_Cache
@@ -220,7 +234,7 @@ class LlamaGlide(LlamaForCausalLM):
         output_ids[:, 0] = self.lm_head(hidden_states[rows, input_len - 1, :]).argmax(dim=-1)
         cache_lens += input_len.int()
         num = 0
-        eos = getattr(self.config, "eos_token_id", None)
+        eos = self._stop_id(eos_id, "vanilla")
         _sync(input_ids)
         start_time = time.time()
         for step in range(1, max_gen_len):
@@ -278,7 +292,7 @@ class LlamaGlide(LlamaForCausalLM):
         num = 0
         next_spec_start_token[:, 0] = output_ids[:, 0]
         emitted = 1                      # host mirror of cache_lens - input_len + 1
-        eos = getattr(self.config, "eos_token_id", None)
+        eos = self._stop_id(eos_id, "spec")
         _sync(input_ids)
         start_time = time.time()
         for out_index in range(1, max_gen_len):
@@ -391,7 +405,7 @@ class LlamaGlide(LlamaForCausalLM):
         gamma = len(cand)
         R = Fn - 1 + gamma + 1               # verification rows: [a accepted | F-1 tree | pads]
         st = SimpleNamespace(cand=cand, acc_n=acc_n, Fn=Fn, gamma=gamma, R=R, P=prompt_bound, dev=dev, bsz=bsz)
-        st.output_ids = torch.full((bsz, max_gen_len), eos_id, dtype=torch.int64, device=dev)       # :937 (G8)
+        st.output_ids = torch.full((bsz, max_gen_len), self._tree_output_fill(eos_id), dtype=torch.int64, device=dev)  # :937 (G8)
         st.spec_mask = torch.zeros((bsz, max_gen_len), dtype=torch.int64, device=dev)
         st.output_ids[:, 0] = first_token
         st.cache_lens = cache_lens.clone()
@@ -408,7 +422,7 @@ class LlamaGlide(LlamaForCausalLM):
         st.diag_one = torch.eye(Fn, dtype=torch.int64, device=dev)[None].expand(bsz, -1, -1)
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
         st.tril = torch.tril(torch.ones((R, R), dtype=torch.int64, device=dev))
-        st.eos = getattr(self.config, "eos_token_id", None)
+        st.eos = self._stop_id(eos_id, "tree")
         st.arange_g = torch.arange(gamma + 1, device=dev)[None, :]
         return st
 

@@ -107,8 +107,8 @@ def rope_cases():
                    factor=float(g[p + "factor"]))
 
 
-def generate_runs():
-    g = load_golden("generate")
+def generate_runs(family="llama"):
+    g = load_golden("generate" if family == "llama" else "generate_qwen2")
     for name in [str(x) for x in g["runs"]]:
         over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
         cfg = toy.toy_config(**over)
@@ -119,7 +119,8 @@ def generate_runs():
             "RNG drift: regenerate goldens"
         d = dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]),
                  prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]),
-                 tree_shape=[int(x) for x in g[f"{name}_tree_shape"]])
+                 tree_shape=[int(x) for x in g[f"{name}_tree_shape"]], family=family,
+                 eos_id=int(g[f"{name}_eos_id"]) if f"{name}_eos_id" in g else 151645)
         for k in ("vanilla_out", "tree_out", "chain_out", "tr_tree_mask", "tr_all_spec", "tr_llm_pred", "tr_acc_ids",
                   "tr_acc_num", "tr_cache_lens"):
             d[k] = _t(g[f"{name}_{k}"])

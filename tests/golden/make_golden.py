@@ -367,8 +367,70 @@ def gen_norm_rope():
 # --------------------------------------------------------------------------- #
 # G-e / G-f: end-to-end generation traces on toy models
 # --------------------------------------------------------------------------- #
-def gen_generate(llama, llama_glide):
+def import_reference_qwen2():
+    """The Qwen2 twins (longspec/test/qwen2.py, qwen2_glide.py).  Two import-time shims, neither on
+    the decode path: `liger_kernel` (a training-loss dependency, qwen2_glide.py:15, absent here) and
+    the "default" entry of transformers' ROPE_INIT_FUNCTIONS, which the vendored Qwen2RotaryEmbedding
+    looks up (qwen2.py:~150) and transformers >= 5 no longer lists: restated from the published
+    formula inv_freq[i] = theta^(-2i/d), attention_scaling 1."""
+    lk = types.ModuleType("liger_kernel")
+    lk.__spec__ = importlib.machinery.ModuleSpec("liger_kernel", None)
+    lk.__path__ = []
+    lkt = types.ModuleType("liger_kernel.transformers")
+    lkt.__spec__ = importlib.machinery.ModuleSpec("liger_kernel.transformers", None)
+
+    class _TrainingOnly:
+        def __init__(self, *a, **k):
+            raise RuntimeError("training-only dependency")
+    lkt.LigerFusedLinearCrossEntropyLoss = _TrainingOnly
+    sys.modules.setdefault("liger_kernel", lk)
+    sys.modules.setdefault("liger_kernel.transformers", lkt)
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    if "default" not in ROPE_INIT_FUNCTIONS:
+        def _default_rope(config, device=None, seq_len=None, **kw):
+            dim = config.hidden_size // config.num_attention_heads
+            inv = 1.0 / (config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+            return inv, 1.0
+        ROPE_INIT_FUNCTIONS["default"] = _default_rope
+    sys.path.insert(0, os.path.join(REF, "test"))
+    import qwen2
+    import qwen2_glide
+    return qwen2, qwen2_glide
+
+
+def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd):
+    from transformers import Qwen2Config
+    hc = Qwen2Config(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, vocab_size=cfg.vocab_size,
+                     max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                     pad_token_id=cfg.pad_token_id, eos_token_id=cfg.eos_token_id, bos_token_id=cfg.bos_token_id)
+    hc.rope_theta = cfg.rope_theta
+    hc.rope_scaling = None
+    hc.sliding_window = None
+    hc._attn_implementation = "eager"          # all three keys map to the same Qwen2Attention (qwen2.py:608-612)
+
+    class RefGlide(qwen2_glide.Qwen2Glide):
+        def __init__(self, config):          # Qwen2Glide.__init__ minus from_pretrained (qwen2_glide.py:476-493)
+            qwen2.Qwen2ForCausalLM.__init__(self, config)
+            self.glide = qwen2_glide.Qwen2GlideDecoderLayer(config)
+
+    m = RefGlide(hc).half().eval()
+    for mod in m.modules():                   # keep inv_freq in fp32, as from_pretrained(torch_dtype=float16) does
+        if isinstance(mod, qwen2.Qwen2RotaryEmbedding):
+            inv, _ = mod.rope_init_fn(hc, None)
+            mod.inv_freq = inv.float()
+            mod.original_inv_freq = inv.float().clone()
+    missing, unexpected = m.load_state_dict({**tgt_sd, **{"glide." + k: v for k, v in drf_sd.items()}}, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary_emb" in k or "inv_freq" in k for k in missing), missing
+    return m
+
+
+def gen_generate(llama, llama_glide, family="llama"):
     arrays = {}
+    if family == "qwen2":
+        qwen2, qwen2_glide = import_reference_qwen2()
     runs = [
         # name, cfg overrides, weight seed, agreement, prompt len, max_gen_len, tree_shape
         ("rand", {}, 11, 1.0, 300, 40, [4, 16, 16, 16, 16]),
@@ -377,11 +439,21 @@ def gen_generate(llama, llama_glide):
         ("mixed_small_tree", {}, 14, 0.05, 150, 40, [2, 4, 4]),
         ("gqa_mixed", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 15, 0.05, 130, 40,
          [4, 16, 16, 16, 16]),
+    ] if family == "llama" else [
+        # Qwen2 twins: q/k/v bias in the target, GQA groups 7 (Qwen2.5-7B) and 5 (QwQ-32B), eos_id argument
+        ("qwen_g7", {"attention_bias": 1, "hidden_size": 896, "num_attention_heads": 7, "num_key_value_heads": 1}, 21, 0.025,
+         140, 40, [4, 16, 16, 16, 16]),
+        ("qwen_g5", {"attention_bias": 1, "hidden_size": 640, "num_attention_heads": 5, "num_key_value_heads": 1}, 22, 0.03,
+         170, 48, [4, 8, 8]),
+        ("qwen_rand", {"attention_bias": 1}, 23, 1.0, 90, 32, [4, 16, 16, 16, 16]),
     ]
     for name, over, wseed, agree, plen, glen, shape in runs:
         cfg = toy.toy_config(**over)
         tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
-        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        if family == "qwen2":
+            m = build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt, drf)
+        else:
+            m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
         install_triton_stubs()      # after model construction
         ids = toy.make_prompt(cfg, plen, 100 + wseed)
         pl = torch.tensor([plen])
@@ -401,14 +473,23 @@ def gen_generate(llama, llama_glide):
             return r
 
         m.tree_verification = spy
+        kw = {}
+        if name == "qwen_g5":        # exercise the eos_id-argument stop of the Qwen2 twin (qwen2_glide.py:580,949)
+            with torch.inference_mode():
+                probe, _, _ = m.vanilla_generate(ids, pl, max_gen_len=glen)
+            kw = {"eos_id": int(probe[0, glen // 2])}
+        arrays[f"{name}_eos_id"] = kw.get("eos_id", 151645)
         with torch.inference_mode():
-            v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=glen)
-            t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=shape, max_gen_len=glen)
-            s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=glen)
+            v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=glen, **kw)
+            t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=shape, max_gen_len=glen, **kw)
+            s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=glen, **kw)
         n_tok = int(t_count) + int(t_num)
-        assert torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]), f"{name}: tree != vanilla"
         n_s = int(s_count) + int(s_num)
         n_cmp = min(n_s, glen)
+        if kw:                       # stopped on eos: the loops agree up to and including the first eos
+            n_eos = int((v_out[0] == kw["eos_id"]).nonzero()[0]) + 1
+            n_tok, n_cmp = min(n_tok, n_eos), min(n_cmp, n_eos)
+        assert torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]), f"{name}: tree != vanilla"
         assert torch.equal(v_out[0, :n_cmp], s_out[0, :n_cmp]), f"{name}: chain != vanilla"
         print(f"[{name}] tree: count={int(t_count)} num={int(t_num)} tau={(n_tok) / int(t_num):.2f};"
               f" chain: count={int(s_count)} num={int(s_num)}")
@@ -429,7 +510,7 @@ def gen_generate(llama, llama_glide):
             f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
             f"{name}_tr_cache_lens": torch.cat(trace["cache_lens"], 0),
         })
-    save("generate", runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
+    save("generate" if family == "llama" else "generate_qwen2", runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
 
 
 # --------------------------------------------------------------------------- #
@@ -494,11 +575,15 @@ def gen_draft_attention(llama_glide):
 def main():
     install_shims()
     llama, llama_glide, triton_tree_attn, train_llama = import_reference()
+    if "--only-qwen2" in sys.argv:            # add the Qwen2 fixture without touching the others
+        gen_generate(llama, llama_glide, family="qwen2")
+        return
     gen_norm_rope()
     gen_tree_verification(llama_glide)
     gen_target_tree_part(llama)
     gen_dense_twin(llama, train_llama)
     gen_generate(llama, llama_glide)
+    gen_generate(llama, llama_glide, family="qwen2")
     install_triton_stubs()          # after model construction
     gen_triton_tree(triton_tree_attn)
     gen_draft_attention(llama_glide)

@@ -6,12 +6,13 @@ import torch
 import cases
 
 pytestmark = pytest.mark.gpu
-RUNS = list(cases.generate_runs())
+RUNS = list(cases.generate_runs()) + list(cases.generate_runs("qwen2"))
 
 
 def build(run):
     from longspec_amd.llama_glide import LlamaGlide
-    m = LlamaGlide(run["cfg"], device="cuda")          # default ops = the HIP operator layer
+    from longspec_amd.qwen2_glide import Qwen2Glide
+    m = (Qwen2Glide if run["family"] == "qwen2" else LlamaGlide)(run["cfg"], device="cuda")          # default ops = the HIP operator layer
     m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
     return m
 
@@ -28,11 +29,15 @@ def test_generate_token_ids_match_reference(run):
     m = build(run)
     ids = run["prompt"].cuda()
     pl = torch.tensor([run["prompt_len"]], device="cuda")
-    v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=run["max_gen_len"])
-    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"])
-    s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=run["max_gen_len"])
+    kw = dict(max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    v_out, v_num, _ = m.vanilla_generate(ids, pl, **kw)
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
+    s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, **kw)
     n_t = int(t_count) + int(t_num)
     n_s = min(int(s_count) + int(s_num), run["max_gen_len"])
+    if run["eos_id"] in run["vanilla_out"][0].tolist():            # stopped on eos: equal up to and including it
+        n_eos = run["vanilla_out"][0].tolist().index(run["eos_id"]) + 1
+        n_t, n_s = min(n_t, n_eos), min(n_s, n_eos)
     # losslessness on the device itself: tree and chain decoding reproduce vanilla decoding
     assert torch.equal(t_out[0, :n_t], v_out[0, :n_t]), "tree decoding is not lossless"
     assert torch.equal(s_out[0, :n_s], v_out[0, :n_s]), "chain decoding is not lossless"

@@ -65,6 +65,9 @@ def target_param_shapes(cfg) -> Dict[str, tuple]:
             p + "input_layernorm.weight": (Hd,),
             p + "post_attention_layernorm.weight": (Hd,),
         })
+        if getattr(cfg, "attention_bias", False):          # Qwen2 target: q/k/v bias (qwen2.py:277-279)
+            shapes.update({p + "self_attn.q_proj.bias": (H * D,), p + "self_attn.k_proj.bias": (Hkv * D,),
+                           p + "self_attn.v_proj.bias": (Hkv * D,)})
     return shapes
 
 
