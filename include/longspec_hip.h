@@ -124,6 +124,53 @@ int ls_lse_merge(const float* parts_o, const float* parts_lse, int n_parts, int 
  * uint32 [b,M,words] (bit j%32 of word j/32), zero padded. */
 int ls_pack_tree_mask(const int64_t* tree_mask, int b, int M, int N, uint32_t* bits, int words, void* stream);
 
+/* ---- skinny linear layers (weight-streaming GEMM, M <= 80 token rows) ---------------- */
+
+#define LS_EPI_NONE 0     /* y = x W^T (+ bias)                                                     */
+#define LS_EPI_SILU_MUL 1 /* y = silu(x Wg^T) * (x Wu^T): w[0] = ls_linear_pack_gate_up(Wg, Wu), n[0] = N */
+
+typedef struct ls_linear_desc {
+    const void* x;        /* [M, K] dtype, row stride ldx (elements)                                  */
+    const void* w[3];     /* weight segments, each [n[i], K] PACKED by ls_linear_pack_weight          */
+    const void* bias[3];  /* [n[i]] dtype or NULL                                                     */
+    void* y;              /* [M, sum n[i]] dtype, row stride ldy (LS_EPI_SILU_MUL: [M, n[0]])         */
+    void* ev_start;       /* optional hipEvent_t pair recorded on `stream` around the kernel, or NULL */
+    void* ev_stop;
+    int32_t M, K;         /* M <= 80 token rows; K a multiple of 64 (>= 128)                          */
+    int32_t n[3];         /* rows of each weight segment (multiples of 128 when n_seg > 1)            */
+    int32_t n_seg;        /* 1..3 segments sharing x: q|k|v in one launch                             */
+    int32_t dtype;        /* LS_F16 / LS_BF16                                                         */
+    int32_t epilogue;     /* LS_EPI_*                                                                 */
+    int32_t n_splits;     /* split-K factor, 0 = automatic (a function of N, K only -- never of M)    */
+    int64_t ldx, ldy;
+} ls_linear_desc;
+
+/* Weights are streamed in the MFMA A-operand layout: pack each nn.Linear.weight [N, K] (row-major,
+ * contiguous) ONCE after loading the checkpoint.  Packed size = ceil(N/64)*64 * K elements; for the
+ * 64-row slab g, 32-wide k-step s and 16-row tile t the 1 KB block sits at element offset
+ * ((g*(K/32) + s)*4 + t)*512 and holds, for lane l, W[64g + 16t + l%16][32s + 8(l/16) .. +8] at offset
+ * 8*l (rows >= N are zero). */
+size_t ls_linear_packed_bytes(int N, int K);
+int ls_linear_pack_weight(const void* weight, void* packed, int N, int K, int dtype, void* stream);
+
+/* gate_proj and up_proj [N, K] of one MLP packed as ONE matrix of 2N rows (ls_linear_packed_bytes(2N, K))
+ * whose 16-row tiles alternate gate, up, gate, up ...: the operand of LS_EPI_SILU_MUL.  N % 16 == 0. */
+int ls_linear_pack_gate_up(const void* gate_weight, const void* up_weight, void* packed, int N, int K,
+                           int dtype, void* stream);
+
+/* Bytes of workspace (slab counters + split-K partials).  The workspace must be ZERO-FILLED once
+ * before its first use; every call leaves the counter region zero again, so one workspace can serve
+ * all launches of a stream. */
+size_t ls_linear_workspace_bytes(const ls_linear_desc* d);
+
+/* The projections of a decode pass: q/k/v/o_proj (longspec/test/llama.py:361-363,390;
+ * llama_glide.py:248-250,268,285-287,305), LlamaMLP / Qwen2MLP.forward (transformers; vendored
+ * qwen2.py:218-230: down_proj(act_fn(gate_proj(x)) * up_proj(x))), lm_head (llama_glide.py:960,1019,
+ * 1046,1091).  fp32 accumulation in a fixed k order that does not depend on M; every linear's output
+ * is rounded to dtype where nn.Linear rounds it.  LS_ERR_UNSUPPORTED for M > 80 or K % 64 != 0 (those
+ * are plain library GEMMs: prefill). */
+int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- RMSNorm / RoPE (K8, K9) ------------------------------------------------ */
 
 /* LlamaRMSNorm.forward (transformers; imported at longspec/test/llama.py:36; vendored

@@ -34,6 +34,20 @@ class AttnDesc(C.Structure):
     ]
 
 
+LS_EPI_NONE, LS_EPI_SILU_MUL = 0, 1
+
+
+class LinearDesc(C.Structure):
+    """Mirror of ``ls_linear_desc`` (include/longspec_hip.h) -- keep field order in sync."""
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("y", C.c_void_p),
+        ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+        ("M", C.c_int32), ("K", C.c_int32), ("n", C.c_int32 * 3), ("n_seg", C.c_int32),
+        ("dtype", C.c_int32), ("epilogue", C.c_int32), ("n_splits", C.c_int32),
+        ("ldx", C.c_int64), ("ldy", C.c_int64),
+    ]
+
+
 # every symbol include/longspec_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int
@@ -47,6 +61,11 @@ SYMBOLS = {
     "ls_attn_partial": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_reduce_local": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P, _P]),
     "ls_attn_finish": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _I, _L, _L, _P, C.c_size_t, _P]),
+    "ls_linear_packed_bytes": (C.c_size_t, [_I, _I]),
+    "ls_linear_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _P]),
+    "ls_linear_pack_gate_up": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "ls_linear_workspace_bytes": (C.c_size_t, [C.POINTER(LinearDesc)]),
+    "ls_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), _P, C.c_size_t, _P]),
     "ls_lse_merge": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ls_pack_tree_mask": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "ls_rmsnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P]),

@@ -5,8 +5,10 @@ Same module tree, attribute names (``model.layers[i].self_attn.{K_Cache,V_Cache}
 and KV-cache layout (``[bsz, prompt + max_len, Hkv, D]`` token-major, zero-initialised,
 ``llama.py:219-222``) as the reference, so ``LlamaGlide`` below it reads like the
 reference's.  Every attention / norm / rotary operator goes through ``longspec_amd.ops``
-(hand-written HIP kernels behind the C ABI); dense projections are plain ``F.linear``
-(hipBLASLt through PyTorch-ROCm).
+(hand-written HIP kernels behind the C ABI).  Dense projections are ``DecodeLinear``: with at most
+80 token rows (every draft / verify / vanilla pass) they stream a pre-packed copy of the weight through
+the skinny-GEMM kernel ``ls_linear_fwd``; with more (prefill) they are plain library GEMMs
+(``F.linear`` = hipBLASLt through PyTorch-ROCm).
 
 ``ops`` is injectable so that the CPU test-suite can drive this host logic with the oracle's
 operators; the product default is the HIP operator layer, which raises on CPU tensors.
@@ -80,16 +82,68 @@ class LlamaRMSNorm(nn.Module):
         return self.ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
 
 
-class LlamaMLP(nn.Module):
-    def __init__(self, config):
-        super().__init__()
-        bias = getattr(config, "mlp_bias", False)
-        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
-        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=bias)
-        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=bias)
+class DecodeLinear(nn.Linear):
+    """``nn.Linear`` (same parameters, same state_dict keys).  A call with <= 80 token rows on the GPU
+    streams a packed copy of the weight (MFMA operand order, built once per weight version) through
+    ``ops.linear``; anything else is ``F.linear``."""
+
+    def __init__(self, in_features, out_features, bias=True, ops=None):
+        super().__init__(in_features, out_features, bias=bias)
+        self.ops = ops
+        self._packed = None
+        self._packed_key = None
+
+    def packed(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if self._packed_key != key:
+            self._packed = self.ops.pack_weight(w)
+            self._packed_key = key
+        return self._packed
+
+    def streams(self, x) -> bool:
+        return self.ops is not None and self.ops.linear_supported(x, self.in_features)
 
     def forward(self, x):
+        if self.streams(x):
+            return self.ops.linear(x, self.packed(), self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
+class LlamaMLP(nn.Module):
+    """``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` (transformers LlamaMLP; vendored qwen2.py:218-230).
+    Decode-shaped calls run gate|up + SiLU + product as ONE weight-streaming launch."""
+
+    def __init__(self, config, ops=None):
+        super().__init__()
+        bias = getattr(config, "mlp_bias", False)
+        self.ops = ops
+        self.gate_proj = DecodeLinear(config.hidden_size, config.intermediate_size, bias=bias, ops=ops)
+        self.up_proj = DecodeLinear(config.hidden_size, config.intermediate_size, bias=bias, ops=ops)
+        self.down_proj = DecodeLinear(config.intermediate_size, config.hidden_size, bias=bias, ops=ops)
+        self._gate_up = None
+        self._gate_up_key = None
+
+    def _packed_gate_up(self):
+        g, u = self.gate_proj.weight, self.up_proj.weight
+        key = (g.data_ptr(), g._version, u.data_ptr(), u._version, g.dtype, g.device)
+        if self._gate_up_key != key:
+            self._gate_up = self.ops.pack_gate_up(g, u)
+            self._gate_up_key = key
+        return self._gate_up
+
+    def forward(self, x):
+        if self.gate_proj.bias is None and self.gate_proj.streams(x) and self.gate_proj.out_features % 16 == 0:
+            return self.down_proj(self.ops.mlp_gate_up(x, self._packed_gate_up()))
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+def project_qkv(ops, x, q_proj, k_proj, v_proj):
+    """q/k/v projections of one input: one launch over the three packed weights when the input is decode-shaped
+    (the outputs are then column slices of one [rows, Nq+Nk+Nv] buffer), three plain linears otherwise."""
+    if q_proj.streams(x) and all(m.out_features % 128 == 0 for m in (q_proj, k_proj, v_proj)):
+        return ops.linear_multi(x, [q_proj.packed(), k_proj.packed(), v_proj.packed()], [q_proj.bias, k_proj.bias, v_proj.bias])
+    return q_proj(x), k_proj(x), v_proj(x)
 
 
 def chunked_causal_prefill(ops, q, k, v, k_cache, v_cache, window_left=-1):
@@ -113,10 +167,10 @@ class LlamaAttention(nn.Module):
         self.num_key_value_heads = config.num_key_value_heads
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
         bias = getattr(config, "attention_bias", False) if self.QKV_BIAS is None else self.QKV_BIAS
-        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
-        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
-        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
-        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.q_proj = DecodeLinear(self.hidden_size, self.num_heads * self.head_dim, bias=bias, ops=ops)
+        self.k_proj = DecodeLinear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias, ops=ops)
+        self.v_proj = DecodeLinear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias, ops=ops)
+        self.o_proj = DecodeLinear(self.num_heads * self.head_dim, self.hidden_size, bias=False, ops=ops)
         self.K_Cache = None
         self.V_Cache = None
         self.max_len = 512
@@ -129,9 +183,10 @@ class LlamaAttention(nn.Module):
 
     def _qkv(self, hidden_states, position_embeddings):
         bsz, q_len, _ = hidden_states.size()
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
-        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        q, k, v = project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj)
+        q = q.view(bsz, q_len, self.num_heads, self.head_dim)
+        k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
         cos, sin = position_embeddings
         self.ops.rope_apply_(q, k, cos, sin)
         return q, k, v
@@ -196,7 +251,7 @@ class LlamaDecoderLayer(nn.Module):
         super().__init__()
         self.hidden_size = config.hidden_size
         self.self_attn = self.ATTENTION_CLS(config, layer_idx, ops=ops)
-        self.mlp = LlamaMLP(config)
+        self.mlp = LlamaMLP(config, ops=ops)
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
 
@@ -264,7 +319,7 @@ class LlamaForCausalLM(nn.Module):
         self.ops = ops if ops is not None else _default_ops()
         self.model = self.MODEL_CLS(config, ops=self.ops)
         self.vocab_size = config.vocab_size
-        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.lm_head = DecodeLinear(config.hidden_size, config.vocab_size, bias=False, ops=self.ops)
 
     def set_max_gen_len(self, max_gen_len):                          # llama.py:646-648
         for layer in self.model.layers:

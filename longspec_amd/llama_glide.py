@@ -20,7 +20,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .llama import LlamaForCausalLM, LlamaMLP, LlamaRMSNorm, LlamaRotaryEmbedding, chunked_causal_prefill, _default_ops
+from .llama import (DecodeLinear, LlamaForCausalLM, LlamaMLP, LlamaRMSNorm, LlamaRotaryEmbedding, chunked_causal_prefill,
+                    project_qkv, _default_ops)
 
 
 class GlideAttention(nn.Module):
@@ -39,10 +40,10 @@ class GlideAttention(nn.Module):
         self.head_dim = self.hidden_size // self.num_heads
         self.num_key_value_heads = config.num_key_value_heads
         self.num_key_value_groups = self.num_heads // self.num_key_value_heads
-        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=True)     # bias=True even for Llama (:49-52)
-        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
-        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True)
-        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self.q_proj = DecodeLinear(self.hidden_size, self.num_heads * self.head_dim, bias=True, ops=ops)     # bias=True even for Llama (:49-52)
+        self.k_proj = DecodeLinear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True, ops=ops)
+        self.v_proj = DecodeLinear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=True, ops=ops)
+        self.o_proj = DecodeLinear(self.num_heads * self.head_dim, self.hidden_size, bias=False, ops=ops)
         self.K_Cache = None
         self.V_Cache = None
         self.max_len = 512
@@ -70,13 +71,15 @@ class GlideAttention(nn.Module):
 
     def _qkv(self, hidden_states, position_embeddings, need_kv=True):
         bsz, q_len, _ = hidden_states.size()
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
         cos, sin = position_embeddings
         if need_kv:
-            k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-            v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            q, k, v = project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj)
+            q = q.view(bsz, q_len, self.num_heads, self.head_dim)
+            k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+            v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
             self.ops.rope_apply_(q, k, cos, sin)
             return q, k, v
+        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
         # cross-attention: the reference projects k/v it never uses (:248-249 vs :265); skip them
         self.ops.rope_apply_(q, q[:, :, :0], cos, sin)
         return q, None, None
@@ -140,7 +143,7 @@ class LlamaGlideDecoderLayer(nn.Module):
         self.layer_idx = 0
         self.self_attn = self.ATTENTION_CLS(config, self.layer_idx, ops=self.ops)
         self.cross_attn = self.ATTENTION_CLS(config, self.layer_idx, ops=self.ops)
-        self.mlp = LlamaMLP(config)
+        self.mlp = LlamaMLP(config, ops=self.ops)
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
         self.post_self_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)
         self.post_cross_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=self.ops)

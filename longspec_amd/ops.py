@@ -9,6 +9,8 @@ One function per reference seam of the draft-then-verify round:
   rmsnorm / rope_*       LlamaRMSNorm / LlamaRotaryEmbedding / apply_rotary_pos_emb (transformers)
   tree_collapse          LlamaGlide.tree_verification  llama_glide.py:1128-1175
   lse_merge              N-way form of llama.py:385-387,420 for sequence-sharded prefix KV
+  linear / linear_multi / mlp_gate_up   the projections of a decode pass (M <= 80 token rows):
+                         q/k/v/o_proj llama.py:361-363,390, LlamaMLP (qwen2.py:218-230), lm_head llama_glide.py:1091
 
 Everything runs on the CURRENT torch stream, without host synchronisation.  There is
 no fallback: a missing extension or a CPU tensor raises.
@@ -62,6 +64,138 @@ class _Workspace:
 
 _ws = _Workspace()
 _causal_bits = {}
+
+
+class _ZeroedWorkspace:
+    """Scratch of the skinny-GEMM kernel (slab counters + split-K partials).  Zero-filled once when
+    (re)allocated; every launch leaves its counters zero again (include/longspec_hip.h)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device, nbytes: int) -> torch.Tensor:
+        key = (device.index, _stream())
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.zeros(max(nbytes, 32 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+_gemm_ws = _ZeroedWorkspace()
+LINEAR_MAX_ROWS = 80
+
+
+def linear_supported(x: torch.Tensor, in_features: int) -> bool:
+    """True when the weight-streaming kernel takes this shape; otherwise the caller has a plain library
+    GEMM on its hands (prefill: M in the thousands), which is hipBLASLt's job, not this kernel's."""
+    rows = x.numel() // x.shape[-1]
+    return x.is_cuda and x.dtype in _DT and 1 <= rows <= LINEAR_MAX_ROWS and in_features % 64 == 0 and in_features >= 128
+
+
+class PackedWeight:
+    """An ``nn.Linear.weight`` [N, K] re-laid-out once by ``ls_linear_pack_weight`` into the MFMA A-operand
+    order the skinny kernel streams (include/longspec_hip.h).  ``data`` is a flat tensor of the weight's
+    dtype with ceil(N/16)*16*K elements."""
+    __slots__ = ("data", "n", "k", "dtype")
+
+    def __init__(self, data, n, k):
+        self.data, self.n, self.k, self.dtype = data, n, k, data.dtype
+
+
+def pack_weight(weight: torch.Tensor) -> PackedWeight:
+    _dev(weight)
+    if weight.dim() != 2 or weight.shape[1] % 32 != 0:
+        raise ValueError("pack_weight: [N, K] weight with K a multiple of 32 expected")
+    w = weight.detach().contiguous()
+    N, K = w.shape
+    lib = _C.load()
+    nbytes = lib.ls_linear_packed_bytes(N, K)
+    out = torch.empty(nbytes // 2, dtype=w.dtype, device=w.device)
+    _C.check(lib.ls_linear_pack_weight(w.data_ptr(), out.data_ptr(), N, K, _dtype(w), _stream()), "ls_linear_pack_weight")
+    return PackedWeight(out, N, K)
+
+
+def pack_gate_up(gate_weight: torch.Tensor, up_weight: torch.Tensor) -> PackedWeight:
+    """gate_proj / up_proj of one MLP as one packed matrix with alternating 16-row tiles (operand of mlp_gate_up)."""
+    _dev(gate_weight, up_weight)
+    if gate_weight.shape != up_weight.shape or gate_weight.dim() != 2 or gate_weight.shape[0] % 16 or gate_weight.shape[1] % 32:
+        raise ValueError("pack_gate_up: two [N, K] weights with N % 16 == 0 and K % 32 == 0 expected")
+    g, u = gate_weight.detach().contiguous(), up_weight.detach().contiguous()
+    N, K = g.shape
+    lib = _C.load()
+    out = torch.empty(lib.ls_linear_packed_bytes(2 * N, K) // 2, dtype=g.dtype, device=g.device)
+    _C.check(lib.ls_linear_pack_gate_up(g.data_ptr(), u.data_ptr(), out.data_ptr(), N, K, _dtype(g), _stream()),
+             "ls_linear_pack_gate_up")
+    return PackedWeight(out, N, K)
+
+
+def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
+    _dev(x)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1 or x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    d = _C.LinearDesc()
+    d.x = x2.data_ptr()
+    n_tot = 0
+    for i, w in enumerate(weights):
+        if not isinstance(w, PackedWeight):
+            raise TypeError("linear: weights must be PackedWeight (ops.pack_weight(nn.Linear.weight))")
+        if w.k != K or w.dtype != x.dtype:
+            raise ValueError(f"packed weight [{w.n}, {w.k}] {w.dtype} does not match x [..., {K}] {x.dtype}")
+        d.w[i] = w.data.data_ptr()
+        b = biases[i] if biases is not None else None
+        if b is not None and (b.dtype != x.dtype or not b.is_contiguous() or b.numel() != w.n):
+            raise ValueError("bias must be a contiguous [N] tensor of x's dtype")
+        d.bias[i] = b.data_ptr() if b is not None else None
+        d.n[i] = w.n
+        n_tot += w.n
+    d.n_seg = len(weights)
+    n_out = weights[0].n if epilogue == _C.LS_EPI_SILU_MUL else n_tot
+    y = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    d.y = y.data_ptr()
+    d.M, d.K = M, K
+    d.dtype = _dtype(x)
+    d.epilogue = epilogue
+    d.n_splits = n_splits
+    d.ldx, d.ldy = x2.stride(0), n_out
+    if timing is not None:          # (torch.cuda.Event, torch.cuda.Event), both already created by a record()
+        d.ev_start, d.ev_stop = timing[0].cuda_event, timing[1].cuda_event
+    lib = _C.load()
+    need = lib.ls_linear_workspace_bytes(C.byref(d))
+    if need == 0:
+        _C.check(lib.ls_linear_fwd(C.byref(d), None, 0, _stream()), "ls_linear_fwd")      # raises with the reason
+    ws = _gemm_ws.get(x.device, need)
+    _C.check(lib.ls_linear_fwd(C.byref(d), ws.data_ptr(), ws.numel(), _stream()), "ls_linear_fwd")
+    return y
+
+
+def linear(x: torch.Tensor, weight: PackedWeight, bias: Optional[torch.Tensor] = None, n_splits: int = 0, timing=None):
+    """``F.linear(x, weight, bias)`` for M <= 96 token rows: ``[..., K] -> [..., N]``."""
+    y = _linear_call(x, [weight], [bias], _C.LS_EPI_NONE, n_splits, timing)
+    return y.view(*x.shape[:-1], weight.n)
+
+
+def linear_multi(x: torch.Tensor, weights, biases=None, n_splits: int = 0, timing=None):
+    """Several linears of the same input in ONE launch (q|k|v): returns views ``[..., n_i]`` of one
+    ``[M, sum n_i]`` buffer."""
+    weights = list(weights)
+    biases = list(biases) if biases is not None else [None] * len(weights)
+    y = _linear_call(x, weights, biases, _C.LS_EPI_NONE, n_splits, timing)
+    outs, o = [], 0
+    for w in weights:
+        outs.append(y[:, o:o + w.n].unflatten(0, x.shape[:-1]))
+        o += w.n
+    return outs
+
+
+def mlp_gate_up(x: torch.Tensor, gate_up: PackedWeight, n_splits: int = 0, timing=None):
+    """``act_fn(gate_proj(x)) * up_proj(x)`` (SiLU) with the reference's roundings: both projections and the
+    activation are rounded to the storage dtype before the product (qwen2.py:229).  ``gate_up`` = pack_gate_up(...)."""
+    y = _linear_call(x, [gate_up], None, _C.LS_EPI_SILU_MUL, n_splits, timing)
+    return y.view(*x.shape[:-1], gate_up.n)
 
 
 def causal_mask_bits(n: int, device) -> torch.Tensor:

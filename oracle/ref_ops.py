@@ -468,6 +468,26 @@ def grow_tree_level(current_logp, history_logp_sum, k: int, base: int):
 # --------------------------------------------------------------------------- #
 # e: N-way log-sum-exp merge of partial attention outputs (multi-GPU KV shards)
 # --------------------------------------------------------------------------- #
+def linear(x, weight, bias=None):
+    """``nn.Linear`` as the decode path calls it (q/k/v/o_proj ``longspec/test/llama.py:361-363,390``, the MLP
+    and ``lm_head`` ``llama_glide.py:1091``): the exact dot products in fp64, rounded ONCE to the storage
+    dtype.  The reference's own GEMM is cuBLAS (third-party, accumulation order unpinned); an fp32-accumulating
+    kernel may differ from this by one ulp of the result where the rounding is a near-tie."""
+    y = x.double() @ weight.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    return y.to(x.dtype)
+
+
+def mlp_gate_up(x, gate_weight, up_weight):
+    """``act_fn(gate_proj(x)) * up_proj(x)`` (transformers LlamaMLP; vendored ``qwen2.py:229``) with the
+    reference's rounding points: each projection, the SiLU and the product are rounded to the storage dtype."""
+    g = linear(x, gate_weight).float()
+    u = linear(x, up_weight).float()
+    s = (g / (1.0 + torch.exp(-g))).to(x.dtype).float()
+    return (s * u).to(x.dtype)
+
+
 def lse_merge(o_parts, lse_parts):
     """N-way generalisation of the reference's 2-way merge
     ``o = o_p*sigmoid(lse_p - lse_t) + o_t*(1 - sigmoid(.))`` (``llama.py:385-387,420``):

@@ -118,3 +118,8 @@ def sharded_verify_attention(q, k_new, v_new, k_cache, v_cache, local_lens, mask
 
 def sharded_prefix_attention(q, k_cache, v_cache, local_lens, causal=False, kv_len_hint=None):
     return _ShardCall(q, k_cache, v_cache, local_lens, causal=causal)
+
+
+def linear_supported(x, in_features):
+    """The weight-streaming linear kernel is GPU-only: on the CPU the host logic uses torch's own F.linear."""
+    return False

@@ -1,0 +1,140 @@
+"""ls_linear_fwd (weight-streaming skinny GEMM, packed weights) against the oracle's exact linear.
+
+Tolerance: the kernel accumulates in fp32 (MFMA) in a fixed order and rounds once, the oracle rounds the
+exact fp64 dot product once.  The fp32 accumulation error is bounded by a few 2^-24 of sum_k |x_k w_k|
+(it matters only where the dot product cancels to ~0); on top of it the two roundings may land on
+neighbouring values where the sum is a near-tie.  So: |got - want| <= 1 ulp(want) + 4 * 2^-24 * |x| . |w|^T,
+and equality on >= 99 % of the elements."""
+import pytest
+import torch
+
+import toy
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp(t):
+    """One unit in the last place of each element of a half/bfloat16 tensor (as fp64)."""
+    a = t.double().abs().clamp_min(6.1e-5 if t.dtype == torch.float16 else 1e-30)
+    mant = 10 if t.dtype == torch.float16 else 7
+    return torch.exp2(torch.floor(torch.log2(a)) - mant)
+
+
+def _acc_tol(x, w):
+    return 4.0 * 2.0 ** -24 * (x.double().abs().reshape(-1, x.shape[-1]) @ w.double().abs().t())
+
+
+def _check(got, want, acc_tol=0.0):
+    diff = (got.double() - want.double()).abs().reshape(-1, want.shape[-1])
+    bound = _ulp(want).reshape(-1, want.shape[-1]) * 1.001 + acc_tol
+    assert bool((diff <= bound).all()), f"more than 1 ulp: worst excess {(diff - bound).max().item():.3e}"
+    assert (got == want).double().mean().item() >= 0.99
+
+
+def _mk(shape, seed, scale=1.0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+SHAPES = [  # (N, K): Llama-3-8B projections (q/o, k/v, down), toy sizes, ragged N
+    (4096, 4096), (1024, 4096), (4096, 14336), (512, 256), (512, 896), (100, 192), (264, 640),
+]
+
+
+@pytest.mark.parametrize("N,K", SHAPES)
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 74, 80])
+def test_linear_matches_oracle(N, K, M):
+    from longspec_amd import ops
+    w, x = _mk((N, K), N + K, 0.03), _mk((M, K), M + K)
+    b = _mk((N,), 7, 0.1)
+    pw = ops.pack_weight(w.cuda())
+    _check(ops.linear(x.cuda(), pw).cpu(), ref_ops.linear(x, w), _acc_tol(x, w))
+    _check(ops.linear(x.cuda(), pw, b.cuda()).cpu(), ref_ops.linear(x, w, b), _acc_tol(x, w))
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("M", [1, 74])
+def test_split_k_is_exact_and_deterministic(S, M):
+    from longspec_amd import ops
+    N, K = 1024, 4096
+    w, x = _mk((N, K), 11, 0.03), _mk((M, K), 12)
+    pw = ops.pack_weight(w.cuda())
+    y0 = ops.linear(x.cuda(), pw, n_splits=S)
+    _check(y0.cpu(), ref_ops.linear(x, w), _acc_tol(x, w))
+    for _ in range(5):                                   # arrival order of the workgroups must not matter
+        assert torch.equal(ops.linear(x.cuda(), pw, n_splits=S), y0)
+
+
+def test_rows_do_not_depend_on_the_batch():
+    """A token's projection is bit-identical whether it is computed alone (vanilla decode) or as one of 74
+    verification rows: the k order of the accumulation depends on (N, K) only."""
+    from longspec_amd import ops
+    for (N, K) in [(4096, 4096), (14336, 4096), (4096, 14336), (512, 256)]:
+        w, x = _mk((N, K), 21, 0.03), _mk((74, K), 22)
+        pw = ops.pack_weight(w.cuda())
+        full = ops.linear(x.cuda(), pw)
+        for rows in (slice(0, 1), slice(5, 21), slice(40, 72)):
+            assert torch.equal(ops.linear(x[rows].cuda(), pw), full[rows])
+
+
+@pytest.mark.parametrize("M", [1, 16, 30, 74])
+def test_qkv_in_one_launch(M):
+    from longspec_amd import ops
+    K = 4096
+    ws = [_mk((n, K), 30 + i, 0.03) for i, n in enumerate((4096, 1024, 1024))]
+    bs = [_mk((n,), 40 + i, 0.1) for i, n in enumerate((4096, 1024, 1024))]
+    x = _mk((1, M, K), 50)
+    outs = ops.linear_multi(x.cuda(), [ops.pack_weight(w.cuda()) for w in ws], [b.cuda() for b in bs])
+    for o, w, b in zip(outs, ws, bs):
+        assert o.shape == (1, M, w.shape[0])
+        _check(o.cpu(), ref_ops.linear(x, w, b), _acc_tol(x, w))
+
+
+@pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512)])
+@pytest.mark.parametrize("M", [1, 16, 30, 74])
+def test_mlp_gate_up_silu(N, K, M):
+    """silu(gate) * up with the reference's rounding points; the two inner GEMMs may each be 1 ulp off the
+    exact rounding, which the product can amplify to 2 ulp of the output on rare elements."""
+    from longspec_amd import ops
+    wg, wu, x = _mk((N, K), 61, 0.03), _mk((N, K), 62, 0.03), _mk((M, K), 63)
+    got = ops.mlp_gate_up(x.cuda(), ops.pack_gate_up(wg.cuda(), wu.cuda())).cpu()
+    want = ref_ops.mlp_gate_up(x, wg, wu)
+    diff = (got.double() - want.double()).abs()
+    assert bool((diff <= 2.001 * _ulp(want) + 1e-4).all()), f"max diff {diff.max().item():.3e}"
+    assert (got == want).double().mean().item() >= 0.98
+
+
+def test_bf16_and_strided_input():
+    from longspec_amd import ops
+    N, K, M = 1024, 512, 20
+    w, xbig = _mk((N, K), 71, 0.03, torch.bfloat16), _mk((M, 2 * K), 72, 1.0, torch.bfloat16)
+    x = xbig[:, K:]                                       # row stride 2K, 16-byte aligned start
+    _check(ops.linear(x.cuda(), ops.pack_weight(w.cuda())).cpu(), ref_ops.linear(x, w), _acc_tol(x, w))
+
+
+def test_unsupported_shapes_fail_loudly():
+    from longspec_amd import ops
+    from longspec_amd._C import LongSpecHipError
+    w = _mk((256, 256), 81).cuda()
+    pw = ops.pack_weight(w)
+    with pytest.raises(LongSpecHipError, match="plain library GEMM"):
+        ops.linear(torch.zeros(81, 256, dtype=torch.float16, device="cuda"), pw)
+    assert not ops.linear_supported(torch.zeros(81, 256, dtype=torch.float16, device="cuda"), 256)
+    assert not ops.linear_supported(torch.zeros(4, 160, dtype=torch.float16, device="cuda"), 160)
+    with pytest.raises(TypeError, match="PackedWeight"):
+        ops.linear(torch.zeros(4, 256, dtype=torch.float16, device="cuda"), w)
+
+
+def test_decode_linear_module_repacks_after_weight_update():
+    from longspec_amd import ops
+    from longspec_amd.llama import DecodeLinear
+    lin = DecodeLinear(256, 512, bias=True, ops=ops).half().cuda()
+    x = _mk((3, 256), 91).cuda()
+    y0 = lin(x)
+    _check(y0.cpu(), ref_ops.linear(x.cpu(), lin.weight.detach().cpu(), lin.bias.detach().cpu()), 1e-5)
+    with torch.no_grad():
+        lin.weight.mul_(2.0)
+    _check(lin(x).cpu(), ref_ops.linear(x.cpu(), lin.weight.detach().cpu(), lin.bias.detach().cpu()), 1e-5)
+    big = _mk((200, 256), 92).cuda()                      # prefill-shaped: library GEMM
+    assert lin(big).shape == (200, 512)
