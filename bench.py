@@ -127,6 +127,33 @@ class EventPool:
         return sum(a.elapsed_time(b) for a, b in self.ev[:self.i]) * 1e3 / self.i
 
 
+class GemmPool:
+    """Event pairs + algorithmic bytes of every weight-streaming GEMM launch (ls_linear_fwd) of the timed region."""
+
+    def __init__(self, n):
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in self.ev:
+            a.record()
+            b.record()
+        self.bytes = []
+        self.on = False
+
+    def hook(self, nbytes):
+        if not self.on or len(self.bytes) >= len(self.ev):
+            return None
+        self.bytes.append(nbytes)
+        return self.ev[len(self.bytes) - 1]
+
+    def stats(self):
+        n = len(self.bytes)
+        if n == 0:
+            return None
+        us = [a.elapsed_time(b) * 1e3 for a, b in self.ev[:n]]
+        big = [(b, t) for b, t in zip(self.bytes, us) if b >= 100e6]      # the MLP / lm_head launches
+        return {"launches": n, "bytes": float(sum(self.bytes)), "us": float(sum(us)),
+                "big_gbps": (sum(b for b, _ in big) / (sum(t for _, t in big) * 1e-6) / 1e9) if big else None}
+
+
 def cpu_baseline(cfg, L, sample_calls, tau):
     """The oracle's C restatement of the verification attention (kind "port"), timed on the host cores on
     a bounded sample: `sample_calls` layer-calls at the full prefix length; a round needs one per target
@@ -164,6 +191,7 @@ def main():
     ap.add_argument("--vanilla-steps", type=int, default=16)
     ap.add_argument("--cpu-sample-calls", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,9 +232,12 @@ def main():
         torch.cuda.synchronize()
 
     pool = EventPool(cfg.num_hidden_layers * args.steps) if rank == 0 else None
+    gpool = GemmPool((4 * cfg.num_hidden_layers + 48) * (args.steps // 5 + 1)) if rank == 0 else None
     if pool is not None:
+        from longspec_amd import ops as _ops
         for layer in m.model.layers:
             layer.self_attn.timing = pool.next
+        _ops.set_linear_timing(gpool.hook)
 
     with torch.inference_mode():
         st = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
@@ -216,14 +247,17 @@ def main():
         barrier()
         tok0 = st.emitted
         if pool is not None:
-            pool.on = True
+            pool.on = gpool.on = True
         t0 = time.time()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if gpool is not None:                        # GEMM launches are bracketed on every 5th round only: two event
+                gpool.on = (i % 5 == 0)                  # records around each of ~160 launches/round would cost ~1 ms/round
             m.tree_round(st)
         barrier()
         elapsed = time.time() - t0
         if pool is not None:
-            pool.on = False
+            pool.on = gpool.on = False
+            _ops.set_linear_timing(None)
         tokens = st.emitted - tok0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -245,24 +279,44 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (hybrid verification attention, stage 1; this rank's KV shard) ----
-        mean_us = pool.mean_us()
-        ab = algo_bytes_verify(Ls, H, Hkv)
+        # ---- roofline of the dominant kernel: the weight-streaming GEMM (ls_linear_fwd), ~half of the round's GPU
+        # time.  Algorithmic bytes of a launch = packed weight + x + y; achieved = all bytes / all kernel time of the
+        # launches of the timed region, each bracketed by HIP events on the launch stream.
+        gs = gpool.stats()
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_gemm.json")
         if os.path.exists(tf):
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        g_ach = gs["bytes"] / (gs["us"] * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(g_ach, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(g_ach / 8000.0, 4), "traffic": traffic,
+                           "kernel": "skinny_gemm_kernel (ls_linear_fwd: q|k|v, o_proj, gate|up+SiLU, down_proj, lm_head of the "
+                                     "verify pass and the 5 draft passes)",
+                           "algorithmic_bytes_per_launch": round(gs["bytes"] / gs["launches"]),
+                           "avg_launch_us": round(gs["us"] / gs["launches"], 2), "launches_timed": gs["launches"],
+                           "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, 5)) / 1e3, 3),
+                           "launches_over_100MB_gbps": round(gs["big_gbps"], 1) if gs["big_gbps"] else None}
+        # ---- second kernel: hybrid verification attention, stage 1 (this rank's KV shard) ---------------------------
+        mean_us = pool.mean_us()
+        ab = algo_bytes_verify(Ls, H, Hkv)
+        a_traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                a_traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                a_traffic = None
         achieved = ab / (mean_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                           "kernel": "attn_partial_kernel (verification attention, stage 1)",
-                           "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
-                           "launches_timed": pool.i,
-                           "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
-    if rank == 0 and world == 1:
+        out["roofline_attention"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(achieved / 8000.0, 4), "traffic": a_traffic,
+                                     "kernel": "attn_partial_kernel (verification attention, stage 1)",
+                                     "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
+                                     "launches_timed": pool.i,
+                                     "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
+    if rank == 0 and world == 1 and not args.no_vanilla:
         # ---- speed-up denominator: vanilla autoregressive decode on the same model and prefix ----------
         with torch.inference_mode():
             cl = lens.clone()

@@ -256,14 +256,23 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
 
     def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, exec_type=None, tree_mask=None,
-                induction_head=False, tree_mask_bits=None):
-        residual = hidden_states
-        hidden_states = self.input_layernorm(hidden_states)
+                induction_head=False, tree_mask_bits=None, pending_residual=None, defer_residual=False):
+        """``pending_residual``: the previous layer's MLP output has not been added to its residual stream yet;
+        the sum (rounded to the storage dtype exactly like ``residual + hidden_states``, llama.py:492) is formed
+        inside this layer's first norm kernel.  ``defer_residual``: return (mlp_out, residual) un-added for the
+        next norm to fuse."""
+        if pending_residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual=pending_residual)
         hidden_states, kv_cache = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                                  cache_lens=cache_lens, exec_type=exec_type, tree_mask=tree_mask,
                                                  tree_mask_bits=tree_mask_bits)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual=residual)   # residual + attn, then norm
         hidden_states = self.mlp(hidden_states)
+        if defer_residual:
+            return hidden_states, residual
         hidden_states = residual + hidden_states
         return hidden_states, kv_cache
 
@@ -299,10 +308,12 @@ class LlamaModel(nn.Module):
         hidden_states = inputs_embeds
         if position_embeddings is None:
             position_embeddings = self.rotary_emb(hidden_states, position_ids)
+        residual = None                                            # every `residual + mlp(x)` rides in the next norm kernel
         for decoder_layer in self.layers:
-            hidden_states, _ = decoder_layer(hidden_states, position_embeddings, cache_lens, flex_attn, exec_type,
-                                             tree_mask, induction_head, tree_mask_bits=tree_mask_bits)
-        hidden_states = self.norm(hidden_states)
+            hidden_states, residual = decoder_layer(hidden_states, position_embeddings, cache_lens, flex_attn, exec_type,
+                                                    tree_mask, induction_head, tree_mask_bits=tree_mask_bits,
+                                                    pending_residual=residual, defer_residual=True)
+        hidden_states, _ = self.norm(hidden_states, residual=residual)
         return SimpleNamespace(last_hidden_state=hidden_states, past_key_values=None)
 
     def set_kv_len_hint(self, hint: Optional[int]):

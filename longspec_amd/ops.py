@@ -130,6 +130,16 @@ def pack_gate_up(gate_weight: torch.Tensor, up_weight: torch.Tensor) -> PackedWe
     return PackedWeight(out, N, K)
 
 
+_linear_timing = None
+
+
+def set_linear_timing(hook):
+    """Profiling: ``hook(algorithmic_bytes) -> (start_event, stop_event) | None`` is asked for a torch event pair
+    before every skinny-GEMM launch (recorded by the C ABI around the kernel, on the launch stream)."""
+    global _linear_timing
+    _linear_timing = hook
+
+
 def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
     _dev(x)
     K = x.shape[-1]
@@ -161,6 +171,9 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
     d.epilogue = epilogue
     d.n_splits = n_splits
     d.ldx, d.ldy = x2.stride(0), n_out
+    if timing is None and _linear_timing is not None:
+        rows_w = sum(w.n for w in weights) * (2 if epilogue == _C.LS_EPI_SILU_MUL else 1)
+        timing = _linear_timing((rows_w * K + M * K + M * n_out) * x.element_size())
     if timing is not None:          # (torch.cuda.Event, torch.cuda.Event), both already created by a record()
         d.ev_start, d.ev_stop = timing[0].cuda_event, timing[1].cuda_event
     lib = _C.load()

@@ -94,14 +94,15 @@ def test_qkv_in_one_launch(M):
 @pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512)])
 @pytest.mark.parametrize("M", [1, 16, 30, 74])
 def test_mlp_gate_up_silu(N, K, M):
-    """silu(gate) * up with the reference's rounding points; the two inner GEMMs may each be 1 ulp off the
-    exact rounding, which the product can amplify to 2 ulp of the output on rare elements."""
+    """silu(gate) * up with the reference's rounding points.  Each inner GEMM may be 1 ulp off the exact
+    rounding on a rare element; SiLU (slope <= 1.1, then rounded) and the rounded product can carry that to
+    at most 4 ulp of the output (1 ulp relative on each factor, two more roundings)."""
     from longspec_amd import ops
     wg, wu, x = _mk((N, K), 61, 0.03), _mk((N, K), 62, 0.03), _mk((M, K), 63)
     got = ops.mlp_gate_up(x.cuda(), ops.pack_gate_up(wg.cuda(), wu.cuda())).cpu()
     want = ref_ops.mlp_gate_up(x, wg, wu)
     diff = (got.double() - want.double()).abs()
-    assert bool((diff <= 2.001 * _ulp(want) + 1e-4).all()), f"max diff {diff.max().item():.3e}"
+    assert bool((diff <= 4.001 * _ulp(want) + 1e-4).all()), f"max diff {diff.max().item():.3e}"
     assert (got == want).double().mean().item() >= 0.98
 
 
