@@ -194,6 +194,22 @@ int ls_rope_apply(void* q, void* k, const void* cos, const void* sin, int rows, 
 int ls_tree_positions(const int64_t* tree_mask, const int32_t* base, int b, int M, int N,
                       int64_t* positions, void* stream);
 
+/* ---- beam-tree growth / greedy verification on the lm_head logits ------------------------- */
+
+/* Scratch for the two entry points below (per-chunk maxima, sums and candidates). */
+size_t ls_topk_workspace_bytes(int rows, int vocab, int k);
+
+/* `(lm_head(h).float().log_softmax(-1) + history[..., None]).view(-1).topk(k)` of one batch row
+ * (longspec/test/llama_glide.py:1019-1020, 1046-1064): logits [rows, vocab] dtype (row stride ld), history
+ * [rows] fp32 or NULL.  out_vals [k] fp32 descending, out_idx [k] int64 = row * vocab + column; equal
+ * values are ordered by the smaller index.  vocab % 8 == 0, k <= 64, rows <= 128. */
+int ls_logprob_topk(const void* logits, int rows, int vocab, int64_t ld, int dtype, const float* history, int k,
+                    float* out_vals, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* `lm_head(h).argmax(-1)` (llama_glide.py:578,1091): out_idx [rows] int64, first maximum of each row. */
+int ls_argmax_rows(const void* logits, int rows, int vocab, int64_t ld, int dtype, int64_t* out_idx,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- accept / reject tree collapse (K10) ---------------------------------------- */
 
 /* LlamaGlide.tree_verification (longspec/test/llama_glide.py:1128-1175), b == 1 per call

@@ -244,7 +244,7 @@ class LlamaGlide(LlamaForCausalLM):
             self._set_hints(P + step, P + step)
             cur = output_ids[rows, (cache_lens - input_len).long()].view(bsz, -1)
             hidden_states = self.model.forward(cur, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
-            llm_output = self.lm_head(hidden_states[:, -1, :]).argmax(dim=-1)
+            llm_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -1, :]))
             cache_lens += 1
             num += bsz
             output_ids[rows, (cache_lens - input_len).long()] = llm_output.view(-1)
@@ -325,7 +325,7 @@ class LlamaGlide(LlamaForCausalLM):
                     current_logp = self.lm_head(hidden_states[:, -1, :])
                     spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1).view(-1,)
             hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
-            llm_verify_output = self.lm_head(hidden_states[:, -gamma - 1:, :]).argmax(dim=-1)
+            llm_verify_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -gamma - 1:, :]))
             verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
             correct_len = verification.sum(dim=-1) + 1
             llm_verify_output[:, 1:] = llm_verify_output[:, 1:] * verification
@@ -447,9 +447,10 @@ class LlamaGlide(LlamaForCausalLM):
                                    llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
                                    llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="decoding")
         st.draft_cache_lens += a - 1
-        current_logp = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, -1).float().log_softmax(dim=-1)
-        vocab_size = current_logp.size(-1)
-        topk_logp, pred_ids = current_logp.topk(dim=-1, k=cand[0], largest=True, sorted=True)
+        # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits
+        logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
+        vocab_size = logits.size(-1)
+        topk_logp, pred_ids = self.ops.logprob_topk(logits, None, cand[0])
         tree_mask[:, 1:acc_n[1]] += diag_one[:, 1:acc_n[1]]
         current_tree_mask = tree_mask[:, 1:acc_n[1], :acc_n[1]]
         all_spec[:, 1:acc_n[1]] = pred_ids
@@ -465,9 +466,9 @@ class LlamaGlide(LlamaForCausalLM):
                                        llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
                                        llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="tree_decoding",
                                        tree_mask=ctm)
-            current_logp = self.lm_head(hidden_states).float().log_softmax(dim=-1)
-            current_logp_sum = current_logp + history_logp_sum[:, acc_n[ms - 1]:acc_n[ms], None]
-            topk_logp_sum, topk_indices = current_logp_sum.view(bsz, -1).topk(dim=-1, k=pred_num)         # beam tree (:1064)
+            # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
+            topk_logp_sum, topk_indices = self.ops.logprob_topk(self.lm_head(hidden_states),
+                                                                history_logp_sum[:, acc_n[ms - 1]:acc_n[ms]], pred_num)
             father_ids = topk_indices // vocab_size + acc_n[ms - 1]
             pred_ids = topk_indices % vocab_size
             tree_mask[:, acc_n[ms]:acc_n[ms + 1]] = (torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn))
@@ -486,7 +487,7 @@ class LlamaGlide(LlamaForCausalLM):
         hidden_states = self.model.forward(veri_spec, cache_lens=st.cache_lens.clone(), exec_type="tree_decoding",
                                            tree_mask=new_tree_mask).last_hidden_state
         hidden_states = hidden_states[:, a - 1:a + Fn - 1]
-        all_llm_pred = self.lm_head(hidden_states).argmax(dim=-1)
+        all_llm_pred = self.ops.argmax_rows(self.lm_head(hidden_states))
         # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
         st.cache_lens += a - 1
         sh = last_attn.shard

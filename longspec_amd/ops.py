@@ -9,6 +9,7 @@ One function per reference seam of the draft-then-verify round:
   rmsnorm / rope_*       LlamaRMSNorm / LlamaRotaryEmbedding / apply_rotary_pos_emb (transformers)
   tree_collapse          LlamaGlide.tree_verification  llama_glide.py:1128-1175
   lse_merge              N-way form of llama.py:385-387,420 for sequence-sharded prefix KV
+  logprob_topk / argmax_rows   beam growth and greedy verification on the lm_head logits  llama_glide.py:1019-1064,1091
   linear / linear_multi / mlp_gate_up   the projections of a decode pass (M <= 80 token rows):
                          q/k/v/o_proj llama.py:361-363,390, LlamaMLP (qwen2.py:218-230), lm_head llama_glide.py:1091
 
@@ -128,6 +129,47 @@ def pack_gate_up(gate_weight: torch.Tensor, up_weight: torch.Tensor) -> PackedWe
     _C.check(lib.ls_linear_pack_gate_up(g.data_ptr(), u.data_ptr(), out.data_ptr(), N, K, _dtype(g), _stream()),
              "ls_linear_pack_gate_up")
     return PackedWeight(out, N, K)
+
+
+def logprob_topk(logits: torch.Tensor, history: Optional[torch.Tensor], k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(logits.float().log_softmax(-1) + history[..., None]).view(bsz, -1).topk(k)`` (llama_glide.py:1019-1020,
+    1046-1064) straight from the fp16 lm_head output: logits [bsz, rows, V], history [bsz, rows] fp32 or None ->
+    (values [bsz, k] fp32 descending, flat indices [bsz, k] int64 = row * V + column)."""
+    _dev(logits, history)
+    if logits.dim() == 2:
+        logits = logits.unsqueeze(1)
+    if logits.stride(-1) != 1 or logits.stride(1) % 8 != 0:
+        logits = logits.contiguous()
+    b, R, V = logits.shape
+    vals = torch.empty((b, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((b, k), dtype=torch.int64, device=logits.device)
+    if history is not None:
+        history = history.to(torch.float32).contiguous()
+    lib = _C.load()
+    need = lib.ls_topk_workspace_bytes(R, V, k)
+    ws = _ws.get(logits.device, max(need, 1))
+    for i in range(b):
+        _C.check(lib.ls_logprob_topk(logits[i].data_ptr(), R, V, logits.stride(1), _dtype(logits),
+                                     history[i].data_ptr() if history is not None else None, k, vals[i].data_ptr(),
+                                     idx[i].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ls_logprob_topk")
+    return vals, idx
+
+
+def argmax_rows(logits: torch.Tensor) -> torch.Tensor:
+    """``logits.argmax(-1)`` for lm_head outputs [..., V] (first maximum), int64 [...]."""
+    _dev(logits)
+    shape = logits.shape[:-1]
+    V = logits.shape[-1]
+    x = logits.reshape(-1, V)
+    if x.stride(-1) != 1 or x.stride(0) % 8 != 0:
+        x = x.contiguous()
+    out = torch.empty((x.shape[0],), dtype=torch.int64, device=logits.device)
+    lib = _C.load()
+    need = lib.ls_topk_workspace_bytes(x.shape[0], V, 1)
+    ws = _ws.get(logits.device, max(need, 1))
+    _C.check(lib.ls_argmax_rows(x.data_ptr(), x.shape[0], V, x.stride(0), _dtype(x), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                _stream()), "ls_argmax_rows")
+    return out.view(shape)
 
 
 _linear_timing = None

@@ -123,3 +123,17 @@ def sharded_prefix_attention(q, k_cache, v_cache, local_lens, causal=False, kv_l
 def linear_supported(x, in_features):
     """The weight-streaming linear kernel is GPU-only: on the CPU the host logic uses torch's own F.linear."""
     return False
+
+
+def logprob_topk(logits, history, k):
+    """The reference's expression (llama_glide.py:1019-1020,1046-1064), verbatim."""
+    if logits.dim() == 2:
+        logits = logits.unsqueeze(1)
+    lp = logits.float().log_softmax(dim=-1)
+    if history is not None:
+        lp = lp + history[:, :, None]
+    return lp.view(lp.shape[0], -1).topk(dim=-1, k=k, largest=True, sorted=True)
+
+
+def argmax_rows(logits):
+    return logits.argmax(dim=-1)

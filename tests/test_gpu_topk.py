@@ -1,0 +1,64 @@
+"""ls_logprob_topk / ls_argmax_rows against the reference's torch expression (llama_glide.py:1019-1064,1091)
+on the CPU.  Indices are exact wherever the k-th and (k+1)-th values differ by more than the fp32 noise of the
+log-sum-exp (different summation order: a few ulp of a value of magnitude ~10, i.e. <= 1e-5); values within 1e-5."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(logits, history, k):
+    lp = logits.float().log_softmax(dim=-1)
+    if history is not None:
+        lp = lp + history[:, :, None]
+    return lp.view(lp.shape[0], -1).topk(dim=-1, k=k, largest=True, sorted=True), lp.view(lp.shape[0], -1)
+
+
+@pytest.mark.parametrize("R,V,k", [(1, 128256, 4), (4, 128256, 16), (16, 128256, 16), (16, 152064, 16), (16, 32000, 16),
+                                   (1, 512, 4), (16, 512, 16), (2, 512, 2), (8, 512, 8), (16, 8200, 16)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_logprob_topk(R, V, k, dtype):
+    from longspec_amd import ops
+    g = torch.Generator().manual_seed(R * 7 + V + k)
+    logits = (torch.randn(1, R, V, generator=g) * 2.5).to(dtype)
+    hist = None if R == 1 else -torch.rand(1, R, generator=g) * 3
+    (rv, ri), flat = _ref(logits, hist, k)
+    gv, gi = ops.logprob_topk(logits.cuda(), hist.cuda() if hist is not None else None, k)
+    gv, gi = gv.cpu(), gi.cpu()
+    assert torch.allclose(gv, rv, atol=1e-5, rtol=0)
+    # the selected SET must be a valid top-k of the reference values (ties / 1e-6-close values may swap)
+    assert torch.allclose(flat[0, gi[0]], rv[0], atol=1e-5, rtol=0)
+    assert gi[0].unique().numel() == k
+    clear = (rv[0, :-1] - rv[0, 1:]) > 2e-5            # positions whose order is unambiguous
+    same = gi[0] == ri[0]
+    unamb = torch.ones(k, dtype=torch.bool)
+    unamb[:-1] &= clear
+    unamb[1:] &= clear
+    kth_gap = flat[0].topk(k + 1).values
+    if (kth_gap[k - 1] - kth_gap[k]) <= 2e-5:
+        unamb[-1] = False
+    assert bool(same[unamb].all())
+
+
+def test_ties_go_to_the_smaller_index():
+    from longspec_amd import ops
+    V = 16384
+    logits = torch.zeros(1, 3, V, dtype=torch.float16)
+    logits[0, 1, 100] = logits[0, 1, 9000] = logits[0, 2, 5] = 4.0
+    logits[0, 0, 77] = 2.0
+    gv, gi = ops.logprob_topk(logits.cuda(), torch.zeros(1, 3).cuda(), 5)
+    # row 2 has one 4.0 (smaller log-sum-exp -> larger log-prob); row 1's two 4.0 tie exactly: smaller index first
+    assert gi[0].tolist()[:3] == [2 * V + 5, 1 * V + 100, 1 * V + 9000]
+    am = ops.argmax_rows(logits.cuda())
+    assert am.tolist() == [[77, 100, 5]]
+
+
+@pytest.mark.parametrize("R,V", [(1, 128256), (69, 128256), (74, 152064), (5, 512), (69, 32000)])
+def test_argmax_rows(R, V):
+    from longspec_amd import ops
+    g = torch.Generator().manual_seed(R + V)
+    logits = (torch.randn(1, R, V, generator=g) * 2.5).half()
+    got = ops.argmax_rows(logits.cuda()).cpu()
+    want = logits.argmax(dim=-1)
+    # equal maxima (fp16 collisions): PyTorch-CPU and this kernel both return the first one
+    assert torch.equal(got, want)
