@@ -22,59 +22,137 @@ namespace {
 
 constexpr int TK_THREADS = 256;
 constexpr int TK_CHUNK = 8192;          // logits per stage-1 workgroup: 32 per thread
-constexpr int TK_MAXK = 64;
+constexpr int TK_MAXK = 64;          // also bounded by TK_THREADS (sentinel padding) and the merge kernel's registers
 
-struct Cand {
-    float v;
-    int i;
-};
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
-__device__ __forceinline__ Cand wave_best(Cand c) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(c.v, off);
-        const int oi = __shfl_xor(c.i, off);
-        if (better(ov, oi, c.v, c.i)) { c.v = ov; c.i = oi; }
-    }
-    return c;
-}
-
-// ws layout per (row, chunk): float max, float sum, then k x (float value, int column)
+// ws layout per (row, chunk): float max, float sum, then k x (float value, int column), in no particular order
 __device__ __forceinline__ float* ws_rec(float* ws, int row, int chunk, int nchunks, int k) {
     return ws + ((long)row * nchunks + chunk) * (2 + 2 * k);
 }
 
+// 16-bit float pattern -> unsigned key that orders like the value (no NaNs on this path)
+__device__ __forceinline__ unsigned order_key(unsigned bits16) { return (bits16 & 0x8000u) ? (~bits16 & 0xffffu) : (bits16 | 0x8000u); }
+
+// wave-wide max / min of a 32-bit unsigned through the DPP network (6 VALU pairs, no LDS crossbar): quad swaps,
+// row rotations, then row broadcasts; every lane of the result's last row holds ... lane 63 holds the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);   // disabled lanes keep v
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, dpp_mov<0xB1, 0xf>(v));     // quad_perm [1,0,3,2]
+    v = max(v, dpp_mov<0x4E, 0xf>(v));     // quad_perm [2,3,0,1]
+    v = max(v, dpp_mov<0x124, 0xf>(v));    // row_ror:4
+    v = max(v, dpp_mov<0x128, 0xf>(v));    // row_ror:8   -> every lane holds its row's max
+    v = max(v, dpp_mov<0x142, 0xa>(v));    // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_mov<0x143, 0xc>(v));    // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) { return ~wave_umax(~v); }
+
+// the same for a 64-bit key (value key in the high word, inverted flat index in the low word: one max = best
+// value, ties to the smaller index)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max64(unsigned long long v) {
+    const unsigned lo = dpp_mov<CTRL, ROW_MASK>((unsigned)v), hi = dpp_mov<CTRL, ROW_MASK>((unsigned)(v >> 32));
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
+    v = dpp_max64<0xB1, 0xf>(v);
+    v = dpp_max64<0x4E, 0xf>(v);
+    v = dpp_max64<0x124, 0xf>(v);
+    v = dpp_max64<0x128, 0xf>(v);
+    v = dpp_max64<0x142, 0xa>(v);
+    v = dpp_max64<0x143, 0xc>(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// fp32 -> unsigned key that orders like the value
+__device__ __forceinline__ unsigned order_key32(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key32_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Executed by wave 0 on a 256-bin histogram in LDS: the bin holding the `want`-th item counted from the top
+// (from_top) or from the bottom, and how many items lie strictly beyond it on that side.
+__device__ __forceinline__ void find_bin(const int* hist, int want, bool from_top, int lane, int& bin, int& beyond) {
+    int c[4], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = hist[from_top ? 255 - (lane * 4 + j) : lane * 4 + j];
+        tot += c[j];
+    }
+    int incl = tot;                                   // inclusive prefix over lanes 0..lane (in scan direction)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const int excl = incl - tot;
+    const bool here = excl < want && incl >= want;    // exactly one lane
+    int b = 0, bey = 0;
+    if (here) {
+        int run = excl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (run < want && run + c[j] >= want) { b = lane * 4 + j; bey = run; }
+            run += c[j];
+        }
+    }
+    const unsigned long long mask = __ballot(here);
+    const int src = mask ? __ffsll((long long)mask) - 1 : 0;
+    b = __shfl(b, src);
+    bey = __shfl(bey, src);
+    bin = from_top ? 255 - b : b;
+    beyond = bey;
+}
+
+// Stage 1: one workgroup per (chunk of 8192 logits, row).  Exact selection of the chunk's k largest logits
+// (ties to the smaller column) by two 256-bin histogram levels on the ordered 16-bit pattern -- and, only when
+// the k-th value is shared by more elements than fit, two more levels on the column -- instead of k rounds of
+// cross-lane arg-max (measured 2.5 us per round).
 template <typename E>
 __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E::T* __restrict__ logits, long ldl, int V, int k,
                                                                 int nchunks, float* __restrict__ ws) {
-    using V8 = typename E::V8;
     __shared__ float s_red[8];
-    __shared__ Cand s_cand[4 * TK_MAXK];
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[4];          // [0] bin / threshold, [1] count beyond, [2] output cursor, [3] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x, row = blockIdx.y;
     const typename E::T* src = logits + (long)row * ldl;
     const int base = chunk * TK_CHUNK;
+    const int n_valid = min(TK_CHUNK, V - base);
+    const int kk = min(k, n_valid);
 
-    float x[32];
+    uint32_t raw[16];                 // 32 logits as 16-bit patterns; element e = j*8 + i sits at column col0[j] + i
     int col0[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = base + (j * TK_THREADS + tid) * 8;
         col0[j] = c;
-        if (c < V) {                                      // V % 8 == 0: a 16-byte vector is all-in or all-out
-            const V8 v = *reinterpret_cast<const V8*>(src + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[j * 8 + e] = E::to_f32(v[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[j * 8 + e] = -INFINITY;
-        }
+        uint4 v = make_uint4(0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u);      // -inf (fp16); masked by column anyway
+        if (c < V) v = *reinterpret_cast<const uint4*>(src + c);                       // V % 8 == 0: all-in or all-out
+        raw[j * 4 + 0] = v.x; raw[j * 4 + 1] = v.y; raw[j * 4 + 2] = v.z; raw[j * 4 + 3] = v.w;
     }
+    auto bits = [&](int e) -> unsigned { return (raw[e >> 1] >> ((e & 1) * 16)) & 0xffffu; };
+    auto val = [&](int e) -> float {
+        const unsigned short h = (unsigned short)bits(e);
+        return E::to_f32(__builtin_bit_cast(typename E::T, h));
+    };
+    auto valid = [&](int e) -> bool { return col0[e >> 3] < V; };
+    s_hist[tid] = 0;
+    if (tid == 0) s_sel[2] = 0;
+
     // ---- chunk max and sum of exp
     float m = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) m = fmaxf(m, x[e]);
+    for (int e = 0; e < 32; ++e)
+        if (valid(e)) m = fmaxf(m, val(e));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if (lane == 0) s_red[wave] = m;
@@ -82,63 +160,96 @@ __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) s += expf(x[e] - m);     // exp(-inf) = 0 for the padding
+    for (int e = 0; e < 32; ++e)
+        if (valid(e)) s += expf(val(e) - m);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) s_red[4 + wave] = s;
 
-    // ---- k best of each wave (shuffles only), then of the 4 waves
-    Cand mine;
-    auto rescan = [&]() {
-        mine.v = -INFINITY;
-        mine.i = 0x7fffffff;
+    // ---- level 1: high byte of the key
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const int c = col0[e >> 3] + (e & 7);
-            if (x[e] != -INFINITY && better(x[e], c, mine.v, mine.i)) { mine.v = x[e]; mine.i = c; }   // -inf = padding / retired
-        }
-    };
-    rescan();
-    for (int r = 0; r < k; ++r) {
-        const Cand b = wave_best(mine);
-        if (lane == 0) s_cand[wave * TK_MAXK + r] = b;
-        if (b.i == mine.i && b.v == mine.v && b.i != 0x7fffffff) {   // this lane owned the winner: retire it
+    for (int e = 0; e < 32; ++e)
+        if (valid(e)) atomicAdd(&s_hist[order_key(bits(e)) >> 8], 1);
+    __syncthreads();
+    if (wave == 0) {
+        int b, bey;
+        find_bin(s_hist, kk, true, lane, b, bey);
+        if (lane == 0) { s_sel[0] = b; s_sel[1] = bey; }
+    }
+    __syncthreads();
+    const int hi = s_sel[0], above_hi = s_sel[1];
+    __syncthreads();
+    s_hist[tid] = 0;
+    __syncthreads();
+    // ---- level 2: low byte among the elements of that bin
 #pragma unroll
-            for (int e = 0; e < 32; ++e)
-                if (col0[e >> 3] + (e & 7) == b.i) x[e] = -INFINITY;
-            rescan();
-        }
+    for (int e = 0; e < 32; ++e) {
+        const unsigned key = order_key(bits(e));
+        if (valid(e) && (int)(key >> 8) == hi) atomicAdd(&s_hist[key & 255u], 1);
     }
     __syncthreads();
     if (wave == 0) {
-        float* rec = ws_rec(ws, row, chunk, nchunks, k);
-        if (lane == 0) {
-            rec[0] = m;
-            rec[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-        }
-        // 4k candidates, up to 4 per lane
-        Cand c[4];
+        int b, bey;
+        find_bin(s_hist, kk - above_hi, true, lane, b, bey);
+        if (lane == 0) { s_sel[0] = (hi << 8) | b; s_sel[1] = above_hi + bey; s_sel[3] = s_hist[b]; }
+    }
+    __syncthreads();
+    const unsigned T = (unsigned)s_sel[0];          // key of the kk-th largest logit
+    const int n_gt = s_sel[1];                      // logits strictly larger
+    const int n_eq = s_sel[3];                      // logits equal to it
+    const int need = kk - n_gt;                     // how many of the equal ones belong to the top-k (>= 1)
+    int col_limit = 0x7fffffff;                     // equal logits are taken up to this column
+    if (need < n_eq) {                              // a tie at the boundary: the `need` smallest columns win
+        __syncthreads();
+        s_hist[tid] = 0;
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int id = q * 64 + lane;
-            const int w = id / k, r = id % k;
-            if (id < 4 * k) c[q] = s_cand[w * TK_MAXK + r];
-            else { c[q].v = -INFINITY; c[q].i = 0x7fffffff; }
+        for (int e = 0; e < 32; ++e)
+            if (valid(e) && order_key(bits(e)) == T) atomicAdd(&s_hist[(col0[e >> 3] + (e & 7) - base) >> 5], 1);
+        __syncthreads();
+        if (wave == 0) {
+            int b, bey;
+            find_bin(s_hist, need, false, lane, b, bey);
+            if (lane == 0) { s_sel[0] = b; s_sel[1] = bey; }
         }
-        for (int r = 0; r < k; ++r) {
-            Cand l = c[0];
+        __syncthreads();
+        const int cb = s_sel[0], below = s_sel[1];
+        __syncthreads();
+        s_hist[tid] = 0;
+        __syncthreads();
 #pragma unroll
-            for (int q = 1; q < 4; ++q)
-                if (better(c[q].v, c[q].i, l.v, l.i)) l = c[q];
-            const Cand b = wave_best(l);
-            if (lane == 0) {
-                rec[2 + 2 * r] = b.v;
-                reinterpret_cast<int*>(rec)[3 + 2 * r] = b.i;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (c[q].i == b.i && c[q].v == b.v) { c[q].v = -INFINITY; c[q].i = 0x7fffffff; }
+        for (int e = 0; e < 32; ++e) {
+            const int rc = col0[e >> 3] + (e & 7) - base;
+            if (valid(e) && order_key(bits(e)) == T && (rc >> 5) == cb) atomicAdd(&s_hist[rc & 31], 1);
         }
+        __syncthreads();
+        if (wave == 0) {
+            int b, bey;
+            find_bin(s_hist, need - below, false, lane, b, bey);
+            if (lane == 0) s_sel[0] = base + cb * 32 + b;
+        }
+        __syncthreads();
+        col_limit = s_sel[0];
+    }
+    // ---- emit exactly kk candidates (any order), pad with sentinels up to k
+    float* rec = ws_rec(ws, row, chunk, nchunks, k);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const unsigned key = order_key(bits(e));
+        const int c = col0[e >> 3] + (e & 7);
+        if (valid(e) && (key > T || (key == T && c <= col_limit))) {
+            const int slot = atomicAdd(&s_sel[2], 1);
+            rec[2 + 2 * slot] = val(e);
+            reinterpret_cast<int*>(rec)[3 + 2 * slot] = c;
+        }
+    }
+    if (tid < k - kk) {
+        rec[2 + 2 * (kk + tid)] = -INFINITY;
+        reinterpret_cast<int*>(rec)[3 + 2 * (kk + tid)] = 0x7fffffff;
+    }
+    if (tid == 0) {
+        rec[0] = m;
+        rec[1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
     }
 }
 
@@ -148,8 +259,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
                                                                 const float* __restrict__ history, int mode,
                                                                 float* __restrict__ out_vals, int64_t* __restrict__ out_idx) {
     __shared__ float s_m[128], s_lse[128];
-    __shared__ float s_v[4];
-    __shared__ long s_f[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rec_f = 2 + 2 * k;
     if (mode == 1) {
@@ -167,70 +276,80 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
         }
         return;
     }
-    // ---- per row: max and log-sum-exp in fixed chunk order
+    // ---- per row: max and log-sum-exp in fixed chunk order.  All global loads of this kernel are issued in
+    // independent batches (a dependent chain of L2 round trips per candidate cost 35 us in the first version).
+    __shared__ float s_cm[128 * 4], s_cs[128 * 4], s_h[128];     // R * nchunks <= 512 (host-checked)
+    for (int i = tid; i < R * nchunks; i += TK_THREADS) {
+        const float2 ms = *reinterpret_cast<const float2*>(ws + (long)i * rec_f);
+        s_cm[i] = ms.x;
+        s_cs[i] = ms.y;
+    }
+    for (int row = tid; row < R; row += TK_THREADS) s_h[row] = history ? history[row] : 0.f;
+    __syncthreads();
     for (int row = tid; row < R; row += TK_THREADS) {
         float m = -INFINITY;
-        for (int c = 0; c < nchunks; ++c) m = fmaxf(m, ws[((long)row * nchunks + c) * rec_f]);
+        for (int c = 0; c < nchunks; ++c) m = fmaxf(m, s_cm[row * nchunks + c]);
         float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            const float* rec = ws + ((long)row * nchunks + c) * rec_f;
-            s += rec[1] * expf(rec[0] - m);
-        }
+        for (int c = 0; c < nchunks; ++c) s += s_cs[row * nchunks + c] * expf(s_cm[row * nchunks + c] - m);
         s_m[row] = m;
         s_lse[row] = logf(s);
     }
     __syncthreads();
-    // ---- candidates: R * nchunks * k, strided over the threads; value in the reference's operation order
+    // ---- candidates: R * nchunks * k, strided over the threads and held in registers as (ordered key of the
+    // value computed in the reference's operation order, flat index).  Each wave extracts its k best with DPP
+    // reductions (no barrier), wave 0 then merges the 4 sorted lists: the output is sorted descending, ties to
+    // the smaller flat index.
     const int ncand = R * nchunks * k;
-    auto cand_at = [&](int id, float& v, long& flat) {
-        const int row = id / (nchunks * k), rem = id % (nchunks * k);
-        const float* rec = ws + ((long)row * nchunks + rem / k) * rec_f;
-        const float x = rec[2 + 2 * (rem % k)];
-        const int col = reinterpret_cast<const int*>(rec)[3 + 2 * (rem % k)];
-        float lp = (x - s_m[row]) - s_lse[row];                       // log_softmax (llama_glide.py:1046)
-        if (history) lp = lp + history[row];                          // + history_logp_sum (:1061)
-        v = col == 0x7fffffff ? -INFINITY : lp;
-        flat = col == 0x7fffffff ? 0x7fffffffffffffffL : (long)row * V + col;
-    };
-    // each thread scans its candidates every round, skipping retired ones (k, ncand/256 are small)
-    constexpr int MAXOWN = 40;          // ncand <= 256 * 40
-    unsigned long long retired = 0ull;  // bit j: this thread's j-th candidate is out
+    constexpr int MAXOWN = 20;          // ncand <= 256 * 20 (checked on the host)
+    unsigned long long pk[MAXOWN];      // (ordered key of the value) << 32 | ~flat index; 0 = empty
+    float2 ld[MAXOWN];
+    int crow[MAXOWN];
+#pragma unroll
+    for (int j = 0; j < MAXOWN; ++j) {
+        const int id = min(j * TK_THREADS + tid, ncand - 1);           // clamped: every load is unconditional
+        const int rc = id / k, slot = id - rc * k;                     // rc = row * nchunks + chunk
+        crow[j] = rc / nchunks;
+        ld[j] = *reinterpret_cast<const float2*>(ws + (long)rc * rec_f + 2 + 2 * slot);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXOWN; ++j) {
+        const int col = __float_as_int(ld[j].y);
+        const int row = crow[j];
+        float lp = (ld[j].x - s_m[row]) - s_lse[row];                  // log_softmax (llama_glide.py:1046)
+        if (history) lp = lp + s_h[row];                               // + history_logp_sum (:1061)
+        const unsigned long long key = ((unsigned long long)order_key32(lp) << 32) | (0xffffffffu - (unsigned)(row * V + col));
+        pk[j] = (j * TK_THREADS + tid < ncand && col != 0x7fffffff) ? key : 0ull;     // rows * V < 2^31 (host-checked)
+    }
+    __shared__ unsigned long long s_w[4 * TK_MAXK];
     for (int r = 0; r < k; ++r) {
-        float bv = -INFINITY;
-        long bf = 0x7fffffffffffffffL;
-        int bj = -1;
-        for (int j = 0, id = tid; id < ncand && j < MAXOWN; ++j, id += TK_THREADS) {
-            if (retired >> j & 1ull) continue;
-            float v;
-            long f;
-            cand_at(id, v, f);
-            if (v > bv || (v == bv && f < bf)) { bv = v; bf = f; bj = j; }
-        }
-        // workgroup arg-best over (bv, bf)
-        float wv = bv;
-        long wf = bf;
+        unsigned long long b = pk[0];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float ov = __shfl_xor(wv, off);
-            const long of = __shfl_xor(wf, off);
-            if (ov > wv || (ov == wv && of < wf)) { wv = ov; wf = of; }
-        }
-        if (lane == 0) {
-            s_v[wave] = wv;
-            s_f[wave] = wf;
-        }
-        __syncthreads();
-        float gv = s_v[0];
-        long gf = s_f[0];
+        for (int j = 1; j < MAXOWN; ++j) b = pk[j] > b ? pk[j] : b;
+        const unsigned long long w = wave_umax64(b);
+        if (lane == 0) s_w[wave * TK_MAXK + r] = w;
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (s_v[w] > gv || (s_v[w] == gv && s_f[w] < gf)) { gv = s_v[w]; gf = s_f[w]; }
-        if (tid == 0) {
-            out_vals[r] = gv;
-            out_idx[r] = gf;
+        for (int j = 0; j < MAXOWN; ++j) pk[j] = pk[j] == w ? 0ull : pk[j];          // keys are unique
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long mk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = q * 64 + lane;
+            mk[q] = id < 4 * k ? s_w[(id / k) * TK_MAXK + id % k] : 0ull;
         }
-        if (bj >= 0 && bf == gf) retired |= 1ull << bj;
-        __syncthreads();
+        for (int r = 0; r < k; ++r) {
+            unsigned long long b = mk[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) b = mk[q] > b ? mk[q] : b;
+            const unsigned long long w = wave_umax64(b);
+            if (lane == 0) {
+                out_vals[r] = key32_value((unsigned)(w >> 32));
+                out_idx[r] = (int64_t)(0xffffffffu - (unsigned)w);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mk[q] = mk[q] == w ? 0ull : mk[q];
+        }
     }
 }
 
@@ -254,8 +373,10 @@ static int topk_impl(const void* logits, int rows, int vocab, int64_t ld, int dt
     const int nchunks = (vocab + TK_CHUNK - 1) / TK_CHUNK;
     if (mode == 0) {
         if (rows > 128) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: more than 128 rows", what);
-        if ((long)rows * nchunks * k > 256L * 40) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows*chunks*k too large", what);
+        if ((long)rows * nchunks * k > 256L * 20) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows*chunks*k too large", what);
         if ((long)rows * vocab < k) LS_FAIL(LS_ERR_INVALID_ARG, "%s: k exceeds the number of logits", what);
+        if ((long)rows * vocab >= 0x7fffffffL) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows * vocab >= 2^31", what);
+        if ((long)rows * nchunks > 512) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows * chunks > 512", what);
         if (!out_vals) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null out_vals", what);
     }
     if (workspace_bytes < ls_topk_workspace_bytes(rows, vocab, k)) LS_FAIL(LS_ERR_WORKSPACE, "%s: workspace too small", what);

@@ -141,6 +141,12 @@ def logprob_topk(logits: torch.Tensor, history: Optional[torch.Tensor], k: int) 
     if logits.stride(-1) != 1 or logits.stride(1) % 8 != 0:
         logits = logits.contiguous()
     b, R, V = logits.shape
+    if k > 64 or R > 128 or R * ((V + 8191) // 8192) * k > 5120 or R * ((V + 8191) // 8192) > 512 or V % 8:
+        # beyond the fused kernel's candidate budget (trees wider than BASELINE's 16 per level): library kernels
+        lp = logits.float().log_softmax(dim=-1)
+        if history is not None:
+            lp = lp + history[:, :, None].float()
+        return lp.view(b, -1).topk(dim=-1, k=k, largest=True, sorted=True)
     vals = torch.empty((b, k), dtype=torch.float32, device=logits.device)
     idx = torch.empty((b, k), dtype=torch.int64, device=logits.device)
     if history is not None:
