@@ -243,7 +243,7 @@ class LlamaGlide(LlamaForCausalLM):
         for step in range(1, max_gen_len):
             self._set_hints(P + step, P + step)
             cur = output_ids[rows, (cache_lens - input_len).long()].view(bsz, -1)
-            hidden_states = self.model.forward(cur, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
+            hidden_states = self.model.forward(cur, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
             llm_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -1, :]))
             cache_lens += 1
             num += bsz
@@ -314,8 +314,8 @@ class LlamaGlide(LlamaForCausalLM):
                     position_ids = draft_cache_lens[:, None]
                 position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
                 hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens.clone(),
-                                           llm_kv_len=cache_lens.clone(), exec_type="decoding")
+                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
+                                           llm_kv_len=cache_lens, exec_type="decoding")
                 if double_flag and spec_steps == 0:
                     draft_cache_lens += 1 + double_input
                     current_logp = self.lm_head(hidden_states[:, -2:, :])
@@ -324,7 +324,7 @@ class LlamaGlide(LlamaForCausalLM):
                     draft_cache_lens += 1
                     current_logp = self.lm_head(hidden_states[:, -1, :])
                     spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1).view(-1,)
-            hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens.clone(), exec_type="decoding").last_hidden_state
+            hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
             llm_verify_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -gamma - 1:, :]))
             verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
             correct_len = verification.sum(dim=-1) + 1
@@ -431,7 +431,9 @@ class LlamaGlide(LlamaForCausalLM):
 
     def tree_round(self, st) -> bool:
         """One draft-then-verify round (``llama_glide.py:997-1121``): 1 + (gamma-1) draft passes growing
-        the beam tree, one R-row target pass, accept/collapse.  Returns False when generation must stop."""
+        the beam tree, one R-row target pass, accept/collapse.  Returns False when generation must stop.
+        The length tensors are passed without the reference's ``.clone()``: no operator here writes them, and
+        their in-place updates are ordered behind the kernels that read them on the same stream."""
         cand, acc_n, Fn, gamma, R, dev, bsz = st.cand, st.acc_n, st.Fn, st.gamma, st.R, st.dev, st.bsz
         tree_mask, all_spec, diag_one, history_logp_sum = st.tree_mask, st.all_spec, st.diag_one, st.history_logp_sum
         a = st.a
@@ -444,8 +446,8 @@ class LlamaGlide(LlamaForCausalLM):
         position_ids = torch.arange(0, a, device=dev)[None, :] + st.draft_cache_lens[:, None]
         position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                   llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
-                                   llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="decoding")
+                                   llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
+                                   llm_kv_len=st.target_cache_lens_for_draft, exec_type="decoding")
         st.draft_cache_lens += a - 1
         # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits
         logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
@@ -463,8 +465,8 @@ class LlamaGlide(LlamaForCausalLM):
             position_ids = self.ops.tree_positions(ctm, st.draft_cache_lens)                              # p + depth (:1032)
             position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
             hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                       llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens.clone(),
-                                       llm_kv_len=st.target_cache_lens_for_draft.clone(), exec_type="tree_decoding",
+                                       llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
+                                       llm_kv_len=st.target_cache_lens_for_draft, exec_type="tree_decoding",
                                        tree_mask=ctm)
             # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
             topk_logp_sum, topk_indices = self.ops.logprob_topk(self.lm_head(hidden_states),
@@ -484,7 +486,7 @@ class LlamaGlide(LlamaForCausalLM):
         new_tree_mask = st.tril.clone()[None].expand(bsz, -1, -1).contiguous()
         new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
         new_tree_mask = torch.tril(new_tree_mask)
-        hidden_states = self.model.forward(veri_spec, cache_lens=st.cache_lens.clone(), exec_type="tree_decoding",
+        hidden_states = self.model.forward(veri_spec, cache_lens=st.cache_lens, exec_type="tree_decoding",
                                            tree_mask=new_tree_mask).last_hidden_state
         hidden_states = hidden_states[:, a - 1:a + Fn - 1]
         all_llm_pred = self.ops.argmax_rows(self.lm_head(hidden_states))
