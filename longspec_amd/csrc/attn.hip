@@ -248,6 +248,19 @@ __device__ __forceinline__ void softmax_fast(WaveAcc<E, QT>& w, const f32x4 (&s)
 typedef __attribute__((address_space(1))) const void gmem_cv;
 typedef __attribute__((address_space(3))) void lds_v;
 
+// One 16-byte-per-lane LDS DMA: lane i's 16 bytes at `src` land at LDS byte address lds_base + 16*i.  Issued as
+// inline assembly on purpose: for the compiler's own global_load_lds builtin LLVM tracks "an LDS DMA is pending"
+// and, having no alias information, puts s_waitcnt vmcnt(0) in front of every later LDS read it recognises (the
+// ds_read_b64_tr_b16 of the P.V product) -- which drains the whole DMA look-ahead once per 32-key block (measured:
+// ~2 TB/s).  Through asm the pending DMAs are invisible to it; the landing of a tile is awaited explicitly with
+// counted s_waitcnt vmcnt(N) + s_barrier.  (Its vmcnt bookkeeping for ordinary loads can only become more
+// conservative: the counter is in order and these ops are simply not counted.)
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(base) : "memory", "m0");
+}
+
 template <typename F>
 __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, int nd, int ngroups, F&& row_ptr) {
     const int kq = lane >> 4, pos = lane & 15;
@@ -256,8 +269,8 @@ __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int l
         const char* kp;
         const char* vp;
         row_ptr(key, kp, vp);
-        __builtin_amdgcn_global_load_lds((gmem_cv*)(kp + ((pos ^ (key & 15)) << 4)), (lds_v*)(ldsK + grp * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gmem_cv*)(vp + ((pos ^ ((key & 7) << 1)) << 4)), (lds_v*)(ldsV + grp * 1024), 16, 0, 0);
+        dma16(kp + ((pos ^ (key & 15)) << 4), ldsK + grp * 1024);
+        dma16(vp + ((pos ^ ((key & 7) << 1)) << 4), ldsV + grp * 1024);
     }
 }
 
@@ -745,6 +758,377 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
     }
 }
 
+// ===================== warp-specialised prefix path (verification-sized row blocks) =====================
+// For 17..20 row tiles (Llama-3 verify: 296 rows) the single-role loop above spends ~1 us per 64 keys in each
+// of the three pipes -- MFMA (QK^T + P.V), VALU (exp2 / sums / fp16 packing) and LDS reads -- and runs them
+// mostly back to back.  Here the 8 waves split into 4 pairs that share a SIMD: the S wave of a pair computes
+// S^T = K.Q^T and the soft-max numerators of its 80 rows and hands P (fp16, in the exact B-operand register
+// image) to its O wave through LDS; the O wave accumulates O^T += V^T.P^T.  The O wave's MFMAs run under the S
+// wave's VALU work, and inside the S wave the QK^T MFMAs of the NEXT block are issued under the exponentials
+// of the current one.  K is read from LDS by 4 waves instead of 8 (V likewise).
+//   step j (one 32-key block, one workgroup barrier):   S: QK(j+1) || p = 2^((s(j) - m)c), P(j) -> LDS[j & 1]
+//                                                       O: P(j-1) <- LDS[(j-1) & 1], P.V(j-1)
+// The reference m of a row is the maximum over the split's first 64 keys (a QK-only look at blocks 0, 1) and
+// stays FIXED -- no rescaling of O, so nothing flows back from S to O; lse = m*scale + ln(l) holds for any m.
+// If a block sum ever comes within two octaves of the fp16 range the split is redone: a QK-only pass for the
+// true row maxima, then the same loop with those.  K and V stream through separate rings of 32-key blocks
+// (global_load_lds from all 8 waves, one K and one V piece per wave and step): block b is issued LA steps
+// before its K is multiplied (step b-1) and its V slot is released two steps later.
+constexpr int WS_QT = 5;                         // row tiles per pair
+constexpr int WS_LA = 5;                         // blocks of DMA look-ahead (80 KB of K+V in flight per CU)
+constexpr int WS_NK = WS_LA + 1;                 // K ring stages: block b lives from step b-1-LA to step b-1
+constexpr int WS_NV = WS_LA + 3;                 // V ring stages: ... to step b+1
+constexpr int WS_BLK_B = 32 * ROWB;              // 8 KB: 32 keys of K (or V)
+constexpr int WS_PBUF_B = 4 * WS_QT * 1024;      // one P buffer: 4 pairs x 5 row tiles x (64 lanes x 16 B)
+constexpr int WS_RING_B = (WS_NK + WS_NV) * WS_BLK_B;
+constexpr int WS_LDS = WS_RING_B + 2 * WS_PBUF_B + 4 * 80 * 4 + 16;
+constexpr int WS_NEW_CAP = WS_RING_B / (2 * ROWB);   // keys the new-block workgroup can hold in the same LDS
+
+// S^T of one 32-key block with ALL 8 K fragments fetched from LDS before the first MFMA (one exposed LDS latency per
+// block instead of four); the 40 MFMAs that follow are independent of the caller's soft-max VALU work.
+template <typename E, int QT>
+__device__ __forceinline__ void qk_block_pf(f32x4 (&s)[2][QT], const typename E::V8 (&qf)[QT][4], const LaneTbl& tb, unsigned kbase) {
+    int kx = tb.kx;
+    asm volatile("" : "+v"(kx));           // see qk_block
+    const unsigned kb = kbase + tb.kb;
+    typename E::V8 kf[4][2];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[k4][kt], qf[qt][k4], s[kt][qt]);
+}
+
+template <typename E, bool S_ROLE>
+__device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int split, int pair) {
+    constexpr int QT = WS_QT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bi = blockIdx.z, kvh = blockIdx.y % p.Hkv, chunk = blockIdx.y / p.Hkv;
+    const int L = p.cache_seqlens[bi];
+    const float c = p.scale * LOG2E;
+    const int row0 = chunk * p.rows_per_chunk + pair * QT * 16;
+    int rrow[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = row0 + qt * 16 + l15;
+        rrow[qt] = m < p.M ? m % p.sq : 0;        // padding rows: computed, never stored
+    }
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;
+    const LaneTbl tb = make_lane_tbl(l15, g4);
+    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const long kc_row = p.kc_ss * 2;
+    char* pbuf = smem + WS_RING_B;
+    float* s_inv = reinterpret_cast<float*>(pbuf + 2 * WS_PBUF_B);
+    int* redo_flag = reinterpret_cast<int*>(s_inv + 4 * 80);
+
+    // the split's key range in 32-key blocks (splits are cut at 64-key tile boundaries, as in the other path)
+    const int t1 = (L + 63) / 64;
+    const int tps = (t1 + p.n_splits - 1) / p.n_splits;
+    const int b_begin = split * tps * 2;
+    const int nblocks = max(0, min(b_begin + tps * 2, (L + 31) / 32) - b_begin);
+    const int last_key = L - 1;
+
+    // one K piece and one V piece per wave: keys 4*wave .. 4*wave+3 of block b (LDS image swizzled on the source side)
+    auto dma = [&](int b) {
+        const int key = wave * 4 + (lane >> 4), pos = lane & 15;
+        const long ka = min((b_begin + b) * 32 + key, last_key);        // tail rows: re-read the last valid key (masked)
+        dma16(kc_base + ka * kc_row + ((pos ^ (key & 15)) << 4), smem + (b % WS_NK) * WS_BLK_B + wave * 1024);
+        dma16(vc_base + ka * kc_row + ((pos ^ ((key & 7) << 1)) << 4), smem + (WS_NK + b % WS_NV) * WS_BLK_B + wave * 1024);
+    };
+    auto k_addr = [&](int b) -> unsigned { return smem_a + (b % WS_NK) * WS_BLK_B; };
+    auto v_addr = [&](int b) -> unsigned { return smem_a + (WS_NK + b % WS_NV) * WS_BLK_B; };
+    // Both roles execute the same DMA / wait / barrier schedule.  `need` = the youngest block that must have
+    // landed when the barrier releases; blocks up to `issued - 1` are in flight.
+    auto wait_block = [&](int need, int issued) {
+        const int younger = max(0, issued - 1 - need);
+        wait_vmcnt(need < nblocks ? 2 * younger : 0);
+    };
+    auto pass_head = [&]() {
+        const int n0 = min(nblocks, WS_LA + 1);
+        for (int b = 0; b < n0; ++b) dma(b);
+        wait_block(1, n0);                         // blocks 0 and 1 (reference look, first QK)
+        __builtin_amdgcn_s_barrier();
+    };
+    auto step_head = [&](int j) {
+        if (j + 1 + WS_LA < nblocks) dma(j + 1 + WS_LA);                // its K slot died at step j-1, its V slot at step j-1
+    };
+    auto step_tail = [&](int j) {
+        wait_block(j + 2, min(nblocks, j + 2 + WS_LA));                 // K(j+2) is multiplied at step j+1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // P writes / reads of this step are done
+        __builtin_amdgcn_s_barrier();
+    };
+    const unsigned p_base = smem_a + WS_RING_B + pair * QT * 1024 + lane * 16;
+
+    if constexpr (S_ROLE) {
+        typename E::V8 qf[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int m = row0 + qt * 16 + l15;
+            const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
+            const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow[qt] * p.q_ss +
+                                      (long)head * p.q_sh + g4 * 8;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) qf[qt][k4] = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+        }
+        float mref[QT], lsum[QT];
+        auto mask_tail = [&](f32x4 (&s)[2][QT], int b) {    // keys >= L of a block that crosses the end of the cache
+            const int ka0 = (b_begin + b) * 32;
+            if (ka0 + 32 > L) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ka0 + kt * 16 + g4 * 4 + e >= L) s[kt][qt][e] = -INFINITY;
+            }
+        };
+        auto row_max = [&](const f32x4 (&s)[2][QT], float (&mx)[QT]) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float v = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                                      fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+                mx[qt] = fmaxf(mx[qt], wave_xor_max_16_32(v));
+            }
+        };
+        // mode 0: reference from the first 64 keys, fixed;  1: QK-only pass for the true row maxima;  2: as 0 with mref given
+        auto run_pass = [&](int mode) -> float {
+            float pmax = 0.f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                lsum[qt] = 0.f;
+                if (mode != 2) mref[qt] = -INFINITY;
+            }
+            pass_head();
+            f32x4 s_cur[2][QT];
+            if (mode == 0 && nblocks > 1) {        // block 1's share of the reference (block 0's follows)
+                qk_block<E, QT>(s_cur, qf, tb, k_addr(1));
+                mask_tail(s_cur, 1);
+                row_max(s_cur, mref);
+            }
+            if (nblocks > 0) {
+                qk_block<E, QT>(s_cur, qf, tb, k_addr(0));
+                mask_tail(s_cur, 0);
+                if (mode == 0) row_max(s_cur, mref);
+            }
+            __builtin_amdgcn_s_barrier();          // K(0) is consumed: step 0 may overwrite its slot
+            typedef __attribute__((address_space(3))) typename E::V8 lds_v8;
+            // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS; row sums; overflow watch
+            auto softmax_store = [&](int j) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const float mc = mref[qt] * c;
+                    float ps = 0.f;
+                    typename E::V8 pf;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc));
+                            ps += pe;
+                            pf[kt * 4 + e] = E::from_f32(pe);
+                        }
+                    lsum[qt] += ps;
+                    pmax = fmaxf(pmax, ps);                // sum of 8 probabilities: a conservative stand-in for their max
+                    *(lds_v8*)(uintptr_t)(p_base + (j & 1) * WS_PBUF_B + qt * 1024) = pf;
+                }
+            };
+            if (mode == 1) {                               // QK-only pass: true row maxima
+#pragma unroll 1
+                for (int j = 0; j <= nblocks; ++j) {
+                    step_head(j);
+                    if (j < nblocks) {
+                        row_max(s_cur, mref);
+                        if (j + 1 < nblocks) {
+                            qk_block_pf<E, QT>(s_cur, qf, tb, k_addr(j + 1));
+                            mask_tail(s_cur, j + 1);
+                        }
+                    }
+                    step_tail(j);
+                }
+            } else {
+                // steady state: ONE basic block holds the QK^T MFMAs of block j+1 and the VALU work of block j, so that
+                // the scheduler can lay them out as asked below: an MFMA, then the VALU instructions its 16 cycles hide
+#pragma unroll 1
+                for (int j = 0; j + 1 < nblocks; ++j) {
+                    step_head(j);
+                    f32x4 s_next[2][QT];
+                    qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
+                    softmax_store(j);
+#pragma unroll
+                    for (int i = 0; i < 40; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);         // 7 VALU
+                    }
+                    mask_tail(s_next, j + 1);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) s_cur[kt][qt] = s_next[kt][qt];
+                    step_tail(j);
+                }
+                if (nblocks > 0) {                         // last block: nothing left to multiply
+                    step_head(nblocks - 1);
+                    softmax_store(nblocks - 1);
+                    step_tail(nblocks - 1);
+                }
+                step_head(nblocks);                        // the O waves' last P.V
+                step_tail(nblocks);
+            }
+            return pmax;
+        };
+        const float pmax = run_pass(0);
+        if (tid == 0) *redo_flag = 0;
+        __syncthreads();
+        if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;         // fp16 tops out at 65504
+        __syncthreads();
+        if (*redo_flag) {
+            __syncthreads();
+            run_pass(1);
+            run_pass(2);
+        }
+        // row sums and the log-normaliser; the O wave of the pair scales its accumulators by 1/l
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float lt = wave_xor_sum_16_32(lsum[qt]);
+            const float inv = lt > 0.f ? 1.f / lt : 0.f;
+            const float lse = lt > 0.f ? mref[qt] * p.scale + __logf(lt) : -INFINITY;
+            const int m = row0 + qt * 16 + l15;
+            if (g4 == 0) {
+                s_inv[pair * 80 + qt * 16 + l15] = inv;
+                if (m < p.M) {
+                    const int head = kvh * p.g + m / p.sq;
+                    p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow[qt]] = lse;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        f32x4 acc[8][QT];
+        auto run_pass = [&](int mode) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pass_head();
+            __builtin_amdgcn_s_barrier();          // the S waves' look at blocks 0 and 1 is over
+#pragma unroll 1
+            for (int j = 0; j <= nblocks; ++j) {
+                step_head(j);
+                if (mode != 1 && j >= 1) {
+                    const int jj = j - 1;
+                    typename E::V8 pf[QT];
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) pf[qt] = lds_read16<typename E::V8>(p_base + (jj & 1) * WS_PBUF_B + qt * 1024);
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                    int vx = tb.vx;
+                    asm volatile("" : "+v"(vx));           // see qk_block
+                    const unsigned vb = v_addr(jj) + tb.vb;
+                    union VF {
+                        struct { s16x4 a, b; } s;
+                        typename E::V8 v;
+                    } vf[8];                               // all 8 V^T fragments before the first MFMA
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        const unsigned va = vb + ((dt ^ vx) << 5);
+                        vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
+                        vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
+                }
+                step_tail(j);
+            }
+        };
+        run_pass(0);
+        __syncthreads();
+        __syncthreads();
+        if (*redo_flag) {
+            __syncthreads();
+            run_pass(1);
+            run_pass(2);
+        }
+        __syncthreads();                           // the pair's 1/l is in LDS
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float inv = s_inv[pair * 80 + qt * 16 + l15];
+            const int m = row0 + qt * 16 + l15;
+            if (m < p.M) {
+                const int head = kvh * p.g + m / p.sq;
+                float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
+            }
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.has_new && blockIdx.x == 0) {            // the new-key block keeps the 3,3,3,3,2,2,2,2 row split
+        KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int rb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (rb < p.rbA) {
+            if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 3, LS_NEW_TARGET>(pk, smem);
+            else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 3, LS_NEW_DRAFT>(pk, smem);
+            else new_block_path<E, 3, LS_NEW_FLASH>(pk, smem);
+        } else {
+            if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 2, LS_NEW_TARGET>(pk, smem);
+            else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 2, LS_NEW_DRAFT>(pk, smem);
+            else new_block_path<E, 2, LS_NEW_FLASH>(pk, smem);
+        }
+    } else {
+        // Roles by PLACEMENT: the S and the O wave of a pair must sit on the same SIMD (that is the point: the O
+        // wave's MFMAs run under the S wave's VALU work), and which SIMD a wave lands on is the dispatcher's choice.
+        // Each wave reads its SIMD id and draws a rank on it; rank 0 -> S, rank 1 -> O, pair = SIMD.  Should a SIMD
+        // ever receive more than two of the 8 waves, the surplus waves take the slots left free elsewhere.
+        int* s_cnt = reinterpret_cast<int*>(smem + WS_RING_B);      // role scratch in the (still unused) P buffers
+        int* s_free = s_cnt + 4;
+        int& s_nfree = s_cnt[12];
+        const int tid = threadIdx.x;
+        if (tid < 4) s_cnt[tid] = 0;
+        if (tid == 0) s_nfree = 0;
+        __syncthreads();
+        const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3;     // HW_ID.SIMD_ID
+        int rank = 0;
+        if ((tid & 63) == 0) rank = atomicAdd(&s_cnt[simd], 1);
+        rank = __builtin_amdgcn_readfirstlane(rank);
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int sd = 0; sd < 4; ++sd)
+                for (int r = min(s_cnt[sd], 2); r < 2; ++r) s_free[n++] = sd * 2 + r;
+        }
+        __syncthreads();
+        int slot = simd * 2 + rank;
+        if (rank >= 2) {
+            int k = 0;
+            if ((tid & 63) == 0) k = atomicAdd(&s_nfree, 1);
+            slot = s_free[__builtin_amdgcn_readfirstlane(k)];
+        }
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        __syncthreads();                           // the scratch is free again before the first P is written
+        if ((slot & 1) == 0) prefix_path_ws<E, true>(p, smem, (int)blockIdx.x - p.has_new, slot >> 1);
+        else prefix_path_ws<E, false>(p, smem, (int)blockIdx.x - p.has_new, slot >> 1);
+    }
+}
+
 // Row blocks 0..rbA-1 carry QTA tiles, the rest QTB: both instantiations execute the same barrier
 // sequence (identical tile loop), so a workgroup may mix them wave by wave.
 template <typename E, int QTA, int QTB>
@@ -886,11 +1270,20 @@ __global__ void pack_mask_kernel(const int64_t* mask, int M, int N, uint32_t* bi
 // ---- host side ---------------------------------------------------------------------------
 struct Cfg {
     int qtA, qtB, rbA, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
+    int ws;        // warp-specialised prefix path (attn_partial_ws_kernel)
 };
 
 // Workgroup shape for M = g*sq rows sharing one K/V stream (see the header comment).
-Cfg pick_cfg(int M) {
+// The warp-specialised kernel takes the verification-sized row blocks (17..20 tiles) of calls whose prefix has
+// no causal / window edge (every row sees keys [0, L)) and whose new block fits its smaller ring.
+bool ws_eligible(const ls_attn_desc* d) {
+    if (getenv("LS_ATTN_NO_WS")) return false;
+    return d->causal == 0 && d->window_left < 0 && (d->new_mode == LS_NEW_NONE || d->n_new <= WS_NEW_CAP / 64 * 64);
+}
+
+Cfg pick_cfg(int M, bool ws_ok) {
     Cfg c;
+    c.ws = 0;
     int tiles = (M + 15) / 16;
     c.row_chunks = 1;
     if (tiles > 24) {                   // g*sq > 384 rows: several row chunks re-read the K/V stream
@@ -912,6 +1305,11 @@ Cfg pick_cfg(int M) {
     c.rows_per_chunk = (c.rbA * c.qtA + (c.RB - c.rbA) * c.qtB) * 16;
     c.threads = nw * 64;
     c.lds = c.nstages * 2 * c.tile * ROWB + 16;
+    if (ws_ok && tiles > 16 && tiles <= 20) {       // row split of the new-key block stays 3,3,3,3,2,2,2,2
+        c.ws = 1;
+        c.nstages = WS_NEW_CAP / c.tile;            // the new-block workgroup's capacity in the smaller ring
+        c.lds = WS_LDS;
+    }
     return c;
 }
 
@@ -1001,7 +1399,21 @@ int launch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
 }
 
 template <typename E>
+int launch_partial_ws(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+    auto fn = attn_partial_ws_kernel<E>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, grid, dim3(c.threads), c.lds, s, k);
+    LS_CHECK_LAUNCH("attn_partial_ws_kernel");
+    return LS_OK;
+}
+
+template <typename E>
 int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+    if (c.ws) return launch_partial_ws<E>(c, k, grid, s);
     if (c.qtA == 1) return launch_partial<E, 1, 1>(c, k, grid, s);
     if (c.qtA == 2) return launch_partial<E, 2, 2>(c, k, grid, s);
     if (c.qtB == 2) return launch_partial<E, 3, 2>(c, k, grid, s);
@@ -1012,7 +1424,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     int rc = validate(d);
     if (rc) return rc;
     const int g = d->H / d->Hkv;
-    const Cfg c = pick_cfg(g * d->sq);
+    const Cfg c = pick_cfg(g * d->sq, ws_eligible(d));
     const int n_splits = pick_splits(d, c);
     const WsLayout w = ws_layout(d, c, n_splits);
     if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -1091,13 +1503,13 @@ extern "C" {
 
 size_t ls_attn_workspace_bytes(const ls_attn_desc* d) {
     if (validate(d)) return 0;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     return ws_layout(d, c, pick_splits(d, c)).total;
 }
 
 int ls_attn_num_parts(const ls_attn_desc* d) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     return pick_splits(d, c) * c.KS;
 }
 
@@ -1122,7 +1534,7 @@ int ls_attn_fwd(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) 
 int ls_attn_reduce_local(const ls_attn_desc* d, void* ws, size_t ws_bytes, float* o32, float* lse, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!o32 || !lse) LS_FAIL(LS_ERR_INVALID_ARG, "o32/lse null");
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
     char* base = static_cast<char*>(ws);
@@ -1134,7 +1546,7 @@ int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* par
                    int64_t part_lse_stride, void* ws, size_t ws_bytes, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!parts_o || !parts_lse || n_parts < 1 || !d->out) LS_FAIL(LS_ERR_INVALID_ARG, "parts/out null");
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq);
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     const bool has_new = d->new_mode != LS_NEW_NONE;
     if (has_new && (!ws || ws_bytes < w.total)) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
