@@ -193,10 +193,14 @@ class LlamaAttention(nn.Module):
 
     def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, tree_mask=None,
                 exec_type="training", induction_head=False, tree_mask_bits=None):
-        if exec_type == "prefill":
-            y = self.prefill(hidden_states, position_embeddings)
-        elif exec_type == "decoding":
+        if exec_type in ("prefill", "prefill_torch"):            # the *_torch twins of the reference (llama.py:132-197)
+            y = self.prefill(hidden_states, position_embeddings)   # compute the same function with eager attention
+        elif exec_type in ("decoding", "decoding_torch"):
             y = self.decoding(hidden_states, position_embeddings, cache_lens)
+        elif exec_type == "magicdec_prefill":
+            y = self.magicdec_prefill(hidden_states, position_embeddings)
+        elif exec_type == "magicdec_decoding":
+            y = self.fix_stream_spec(hidden_states, position_embeddings, cache_lens)
         elif exec_type == "tree_decoding":
             y = self.tree_decoding(hidden_states, position_embeddings, cache_lens, tree_mask, tree_mask_bits)
         else:
@@ -210,6 +214,31 @@ class LlamaAttention(nn.Module):
         self.V_Cache = q.new_zeros((bsz, q_len + self.max_len, self.num_key_value_heads, self.head_dim))
         attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache)
         return self.o_proj(attn.reshape(bsz, q_len, -1))
+
+    STREAM_SINK, STREAM_WINDOW = 32, 1024      # StreamingLLM cache of the MagicDec baseline (llama.py:255-262)
+
+    def magicdec_prefill(self, hidden_states, position_embeddings):       # llama.py:228-264
+        """Normal prefill, then the drafter's streaming cache: rows [0,32) = the first 32 prompt rows (attention
+        sinks), rows [32,1056) = the last 1024 prompt rows; generated rows are appended behind them."""
+        y = self.prefill(hidden_states, position_embeddings)
+        bsz, q_len, _ = hidden_states.size()
+        sink, win = self.STREAM_SINK, self.STREAM_WINDOW
+        if q_len < win:
+            raise ValueError(f"magicdec needs a prompt of at least {win} tokens, got {q_len}")    # the reference's slice assignment fails there too
+        shape = (bsz, win + sink + self.max_len, self.num_key_value_heads, self.head_dim)
+        self.stream_k_cache = self.K_Cache.new_zeros(shape)
+        self.stream_v_cache = self.K_Cache.new_zeros(shape)
+        for dst, src in ((self.stream_k_cache, self.K_Cache), (self.stream_v_cache, self.V_Cache)):
+            dst[:, :sink] = src[:, :sink]
+            dst[:, sink:sink + win] = src[:, q_len - win:q_len]
+        return y
+
+    def fix_stream_spec(self, hidden_states, position_embeddings, cache_lens):   # llama.py:331-355
+        bsz, q_len, _ = hidden_states.size()
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        attn = self.ops.kvcache_attention(q, self.stream_k_cache, self.stream_v_cache, k, v, causal=True,
+                                          cache_seqlens=cache_lens, kv_len_hint=self.kv_len_hint)
+        return self.o_proj(attn.view(bsz, q_len, self.hidden_size))
 
     def decoding(self, hidden_states, position_embeddings, cache_lens):   # llama.py:304-329
         bsz, q_len, _ = hidden_states.size()

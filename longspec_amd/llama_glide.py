@@ -260,20 +260,40 @@ class LlamaGlide(LlamaForCausalLM):
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def spec_generate(self, input_ids, prompt_length, gamma=4, max_gen_len=64, eos_id=151645, temperature=0.0):   # :621-774
+        return self._chain_generate(input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter="glide")
+
+    @torch.inference_mode()
+    def magicdec_generate(self, input_ids, prompt_length, gamma=4, max_gen_len=64, eos_id=151645, temperature=0.0):  # :776-913
+        """The MagicDec baseline of the reference's harness (``--method magicdec``): chain speculation where the
+        drafter is the TARGET itself attending to a StreamingLLM cache (32 sink rows + the last 1024 prompt rows +
+        what it generates), verified exactly like ``spec_generate``.  Same return tuple."""
+        return self._chain_generate(input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter="magicdec")
+
+    @torch.inference_mode()
+    def vanilla_torch_generate(self, input_ids, prompt_length, max_gen_len=64, eos_id=151645):                      # :587-619
+        """``--method vanilla_torch``: the reference's autoregressive loop over its dense-PyTorch attention twins
+        (``prefill_torch`` / ``decoding_torch``, llama.py:132-197).  There is one attention implementation here,
+        so this is ``vanilla_generate`` (the twins compute the same function; they exist in the reference to
+        time flash-attn against eager attention)."""
+        return self.vanilla_generate(input_ids, prompt_length, max_gen_len=max_gen_len, eos_id=eos_id)
+
+    def _chain_generate(self, input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter):
         assert input_ids is not None, "please give the input"
         if temperature > 0:
             raise NotImplementedError("temperature > 0 is a 'next' row (SURVEY 8(f).4)")
+        magic = drafter == "magicdec"
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
         dev = input_ids.device
         output_ids = input_ids.new_zeros((bsz, max_gen_len + gamma))
         spec_mask = input_ids.new_zeros((bsz, max_gen_len + gamma))
         self.set_max_gen_len(max_gen_len + 128)
-        self.glide.set_max_gen_len(max_gen_len + 128)
+        if not magic:
+            self.glide.set_max_gen_len(max_gen_len + 128)
         P = int(input_ids.size(1))
         self._set_hints(P, P)
         cache_lens = input_ids.new_zeros((bsz)).int()
-        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+        hidden_states = self.model.forward(input_ids, exec_type="magicdec_prefill" if magic else "prefill").last_hidden_state
         input_len = prompt_length
         rows = torch.arange(bsz, device=dev)
         logits = self.lm_head(hidden_states[rows, input_len - 1, :])
@@ -282,12 +302,13 @@ class LlamaGlide(LlamaForCausalLM):
         draft_cache_lens = cache_lens.clone()
         spec_buffer = output_ids.new_zeros((bsz, gamma + 1))
         spec_buffer[:, 0] = output_ids[:, 0]
-        # glide prefill
-        hidden_states = self.model.embed_tokens(input_ids)
-        position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
-        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
-                   cache_lens=draft_cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
+        if not magic:                                    # glide prefill
+            hidden_states = self.model.embed_tokens(input_ids)
+            position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
+            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
+                       cache_lens=draft_cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
+        stream_rows = self.model.layers[0].self_attn.STREAM_SINK + self.model.layers[0].self_attn.STREAM_WINDOW
         double_flag = False
         double_input = None
         next_spec_start_token = output_ids.new_zeros((bsz, 2))
@@ -304,18 +325,26 @@ class LlamaGlide(LlamaForCausalLM):
             for spec_steps in range(0, gamma):
                 if spec_steps == 0:
                     if double_flag:
-                        hidden_states = self.model.embed_tokens(next_spec_start_token[:, 0:2])
+                        draft_ids = next_spec_start_token[:, 0:2]
                         position_ids = torch.arange(0, 2, device=dev)[None, :] + draft_cache_lens[:, None]
                     else:
-                        hidden_states = self.model.embed_tokens(next_spec_start_token[:, 0, None])
+                        draft_ids = next_spec_start_token[:, 0, None]
                         position_ids = draft_cache_lens[:, None]
                 else:
-                    hidden_states = self.model.embed_tokens(spec_buffer[:, spec_steps, None])
+                    draft_ids = spec_buffer[:, spec_steps, None]
                     position_ids = draft_cache_lens[:, None]
+                hidden_states = self.model.embed_tokens(draft_ids)
                 position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-                hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
-                                           llm_kv_len=cache_lens, exec_type="decoding")
+                if magic:        # the target drafts for itself over its streaming cache (:830-836)
+                    stream_lens = (draft_cache_lens - input_len.int() + stream_rows).to(torch.int32)
+                    self.model.set_kv_len_hint(stream_rows + emitted + gamma + 2)
+                    hidden_states = self.model.forward(draft_ids, position_embeddings=position_embeddings, cache_lens=stream_lens,
+                                                       exec_type="magicdec_decoding").last_hidden_state
+                    self.model.set_kv_len_hint(bound)
+                else:
+                    hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                               llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
+                                               llm_kv_len=cache_lens, exec_type="decoding")
                 if double_flag and spec_steps == 0:
                     draft_cache_lens += 1 + double_input
                     current_logp = self.lm_head(hidden_states[:, -2:, :])

@@ -127,3 +127,21 @@ def generate_runs(family="llama"):
         for k in ("vanilla_num", "tree_count", "tree_num", "chain_count", "chain_num"):
             d[k] = int(g[f"{name}_{k}"])
         yield d
+
+
+def baseline_runs():
+    """The harness's comparison baselines (--method magicdec / vanilla_torch), goldens from the reference."""
+    g = load_golden("baselines")
+    for name in [str(x) for x in g["runs"]]:
+        cfg = toy.toy_config()
+        wseed = int(g[f"{name}_wseed"])
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=float(g[f"{name}_agreement"]))
+        assert toy.state_checksum(tgt) + toy.state_checksum(drf) == cksum_str(g[f"{name}_weights_checksum"]), \
+            "RNG drift: regenerate goldens"
+        d = dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]), family="llama",
+                 prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]), gamma=int(g[f"{name}_gamma"]))
+        for k in ("vanilla_out", "vanilla_torch_out", "magicdec_out"):
+            d[k] = _t(g[f"{name}_{k}"])
+        for k in ("vanilla_torch_num", "magicdec_count", "magicdec_num"):
+            d[k] = int(g[f"{name}_{k}"])
+        yield d

@@ -514,6 +514,35 @@ def gen_generate(llama, llama_glide, family="llama"):
 
 
 # --------------------------------------------------------------------------- #
+# the harness's comparison baselines: --method magicdec / vanilla_torch
+# --------------------------------------------------------------------------- #
+def gen_baselines(llama, llama_glide):
+    arrays = {}
+    runs = [("magic_mixed", {}, 31, 0.05, 1100, 40, 4), ("magic_rand", {}, 32, 1.0, 1060, 24, 3)]
+    for name, over, wseed, agree, plen, glen, gamma in runs:
+        cfg = toy.toy_config(**over)
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
+        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        ids = toy.make_prompt(cfg, plen, 100 + wseed)
+        pl = torch.tensor([plen])
+        with torch.inference_mode():
+            v_out, v_num, _ = m.vanilla_generate(ids, pl, max_gen_len=glen)
+            vt_out, vt_num, _ = m.vanilla_torch_generate(ids, pl, max_gen_len=glen)
+            md_out, md_count, md_num, _, _ = m.magicdec_generate(ids, pl, gamma=gamma, max_gen_len=glen)
+        n_md = min(int(md_count) + int(md_num), glen)
+        assert torch.equal(v_out[0, :n_md], md_out[0, :n_md]), f"{name}: magicdec != vanilla"
+        print(f"[{name}] magicdec: count={int(md_count)} num={int(md_num)}; vanilla_torch == vanilla: {torch.equal(v_out, vt_out)}")
+        arrays.update({
+            f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
+            f"{name}_gamma": gamma, f"{name}_prompt": ids,
+            f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
+            f"{name}_vanilla_out": v_out, f"{name}_vanilla_torch_out": vt_out, f"{name}_vanilla_torch_num": int(vt_num),
+            f"{name}_magicdec_out": md_out, f"{name}_magicdec_count": int(md_count), f"{name}_magicdec_num": int(md_num),
+        })
+    save("baselines", runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
+
+
+# --------------------------------------------------------------------------- #
 # draft-layer seams: GlideAttention.decoding / tree_decoding (attention outputs)
 # --------------------------------------------------------------------------- #
 def gen_draft_attention(llama_glide):
@@ -575,6 +604,9 @@ def gen_draft_attention(llama_glide):
 def main():
     install_shims()
     llama, llama_glide, triton_tree_attn, train_llama = import_reference()
+    if "--only-baselines" in sys.argv:
+        gen_baselines(llama, llama_glide)
+        return
     if "--only-qwen2" in sys.argv:            # add the Qwen2 fixture without touching the others
         gen_generate(llama, llama_glide, family="qwen2")
         return
@@ -584,6 +616,7 @@ def main():
     gen_dense_twin(llama, train_llama)
     gen_generate(llama, llama_glide)
     gen_generate(llama, llama_glide, family="qwen2")
+    gen_baselines(llama, llama_glide)
     install_triton_stubs()          # after model construction
     gen_triton_tree(triton_tree_attn)
     gen_draft_attention(llama_glide)

@@ -46,3 +46,15 @@ def test_generate_token_ids_match_reference(run):
     assert torch.equal(t_out.cpu(), run["tree_out"])
     assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
     assert (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
+
+
+@pytest.mark.parametrize("run", list(cases.baseline_runs()), ids=lambda r: r["name"])
+def test_magicdec_baseline_matches_reference(run):
+    m = build(run)
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    out, count, num, _, _ = m.magicdec_generate(ids, pl, gamma=run["gamma"], max_gen_len=run["max_gen_len"])
+    assert (int(count), int(num)) == (run["magicdec_count"], run["magicdec_num"])
+    assert torch.equal(out.cpu(), run["magicdec_out"])
+    vt, vnum, _ = m.vanilla_torch_generate(ids, pl, max_gen_len=run["max_gen_len"])
+    assert torch.equal(vt.cpu(), run["vanilla_torch_out"]) and vnum == run["vanilla_torch_num"]

@@ -85,3 +85,18 @@ def test_chain_spec_generate_matches_reference(run):
     assert (int(count), int(num)) == (run["chain_count"], run["chain_num"])
     n = min(int(count) + int(num), run["max_gen_len"])
     assert torch.equal(out[:, :n], run["chain_out"][:, :n])
+
+
+BASELINES = list(cases.baseline_runs())
+
+
+@pytest.mark.parametrize("run", BASELINES, ids=lambda r: r["name"])
+def test_magicdec_and_vanilla_torch_match_reference(run):
+    """--method magicdec (self-speculation over a StreamingLLM cache) and --method vanilla_torch."""
+    m = build(run)
+    pl = torch.tensor([run["prompt_len"]])
+    out, count, num, _, _ = m.magicdec_generate(run["prompt"], pl, gamma=run["gamma"], max_gen_len=run["max_gen_len"])
+    assert (int(count), int(num)) == (run["magicdec_count"], run["magicdec_num"])
+    assert torch.equal(out, run["magicdec_out"])
+    vt, vnum, _ = m.vanilla_torch_generate(run["prompt"], pl, max_gen_len=run["max_gen_len"])
+    assert torch.equal(vt, run["vanilla_torch_out"]) and vnum == run["vanilla_torch_num"]
