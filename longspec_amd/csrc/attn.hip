@@ -968,10 +968,12 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     f32x4 s_next[2][QT];
                     qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
                     softmax_store(j);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all 8 K-fragment LDS reads first,
+                    __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);            // VALU work while they are in flight
 #pragma unroll
                     for (int i = 0; i < 40; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);         // 7 VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);         // 6 VALU
                     }
                     mask_tail(s_next, j + 1);
 #pragma unroll
