@@ -34,6 +34,8 @@
 // Replaces, on the decode path (reference = longspec/test): llama.py:361-363,390 (q/k/v/o_proj),
 // LlamaMLP.forward (transformers; vendored qwen2.py:218-230), llama_glide.py:248-250,268,285-287,305
 // (draft projections), lm_head at llama_glide.py:960,1019,1046,1091.
+#include <math.h>
+
 #include "ls_common.h"
 
 namespace {
@@ -371,16 +373,20 @@ int pick_mt(int M) { return M <= 16 ? 1 : M <= 32 ? 2 : M <= 80 ? 5 : 0; }
 int pick_splits(int groups, int nks, int forced) {
     const int smax = nks / 16 > 0 ? nks / 16 : 1;     // at least 512 k (8 chunks) per split
     if (forced > 0) return forced < smax ? forced : smax;
-    // time ~ (dispatch rounds over 256 CUs) x (k per workgroup ~ 1/S), plus the partial traffic ~ S;
-    // a weight that already fills the chip is never split
     const int cus = 256;
-    if (groups >= cus) return 1;
+    if (groups >= cus) return 1;                      // a weight that already fills the chip is never split
+    // Measured model of a launch (rocprofv3, M = 74, K = 4096 / 14336; fits within ~1 us):
+    //   t = rounds x (bytes per workgroup / stream rate + 3 us of ramp) + 0.4 us x S of partial traffic,
+    //   stream rate per workgroup = min(27 GB/s, 6 TB/s / resident workgroups), rounds = ceil(groups x S / 256).
+    const double bytes_per_group = 64.0 * nks * 32 * 2;
     int best = 1;
-    double best_cost = 1e30;
+    double best_t = 1e30;
     for (int S = 1; S <= smax && S <= 32; ++S) {
-        const int rounds = (groups * S + cus - 1) / cus;
-        const double cost = (double)rounds / S + 0.02 * S;
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = S; }
+        const int wgs = groups * S;
+        const int rounds = (wgs + cus - 1) / cus;
+        const double rate = fmin(27e9, 6e12 / (wgs < cus ? wgs : cus));
+        const double t = rounds * (bytes_per_group / S / rate + 3e-6) + 0.4e-6 * S;
+        if (t < best_t - 1e-9) { best_t = t; best = S; }
     }
     return best;
 }
