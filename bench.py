@@ -43,6 +43,16 @@ MODELS = {
                           num_key_value_heads=32, vocab_size=32000, max_position_embeddings=16384, rms_norm_eps=1e-5,
                           rope_theta=10000.0, rope_scaling={"type": "linear", "factor": 4.0}, pad_token_id=0,
                           eos_token_id=2, bos_token_id=1),
+    # lmsys/longchat-13b-16k (configs[3]: MHA, 40 heads)
+    "longchat-13b-16k": dict(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40,
+                             num_key_value_heads=40, vocab_size=32000, max_position_embeddings=16384, rms_norm_eps=1e-5,
+                             rope_theta=10000.0, rope_scaling={"type": "linear", "factor": 8.0}, pad_token_id=0,
+                             eos_token_id=2, bos_token_id=1),
+    # Qwen/QwQ-32B-Preview (configs[4]: Qwen2, GQA 40/8, q/k/v bias, bf16)
+    "qwq-32b": dict(hidden_size=5120, intermediate_size=27648, num_hidden_layers=64, num_attention_heads=40,
+                    num_key_value_heads=8, vocab_size=152064, max_position_embeddings=32768, rms_norm_eps=1e-5,
+                    rope_theta=1000000.0, pad_token_id=151643, eos_token_id=151645, bos_token_id=151643,
+                    family="qwen2", dtype="bf16"),
 }
 TREE = [4, 16, 16, 16, 16]
 
@@ -50,8 +60,10 @@ TREE = [4, 16, 16, 16, 16]
 def make_config(name):
     d = dict(MODELS[name])
     d.setdefault("rope_scaling", None)
+    d.setdefault("family", "llama")
+    d.setdefault("dtype", "fp16")
     d["head_dim"] = d["hidden_size"] // d["num_attention_heads"]
-    d.update(attention_bias=False, mlp_bias=False)
+    d.update(attention_bias=d["family"] == "qwen2", mlp_bias=False)
     return SimpleNamespace(**d)
 
 
@@ -63,9 +75,10 @@ def algo_bytes_verify(L, H, Hkv, R=74, D=128):
 
 def build_model(cfg, device, agreement, seed):
     from longspec_amd.llama_glide import LlamaGlide
+    from longspec_amd.qwen2_glide import Qwen2Glide
     torch.manual_seed(seed)
     with torch.device(device):
-        m = LlamaGlide(cfg, dtype=torch.float16)
+        m = (Qwen2Glide if cfg.family == "qwen2" else LlamaGlide)(cfg, dtype=torch.bfloat16 if cfg.dtype == "bf16" else torch.float16)
     g = torch.Generator(device=device).manual_seed(seed)
     with torch.no_grad():
         for name, p in m.named_parameters():
@@ -90,14 +103,14 @@ def synth_kv(m, L_local, L_total, max_rows, device, seed):
     for layer in m.model.layers:
         attn = layer.self_attn
         for nm in ("K_Cache", "V_Cache"):
-            t = torch.zeros((1, L_local + max_rows, Hkv, D), dtype=torch.float16, device=device)
+            t = torch.zeros((1, L_local + max_rows, Hkv, D), dtype=next(m.parameters()).dtype, device=device)
             t[:, :L_local].normal_(0.0, 1.0, generator=g)
             setattr(attn, nm, t)
     sa = m.glide.self_attn
     # the draft only ever reads its last 512 + tree rows; positions are absolute, so the cache is
     # allocated like the reference's (q_len + max_len + 128 rows, llama_glide.py:223-224)
     for nm in ("K_Cache", "V_Cache"):
-        t = torch.zeros((1, L_total + max_rows + 128, Hkv, D), dtype=torch.float16, device=device)
+        t = torch.zeros((1, L_total + max_rows + 128, Hkv, D), dtype=next(m.parameters()).dtype, device=device)
         t[:, max(0, L_total - 1024):L_total].normal_(0.0, 1.0, generator=g)
         setattr(sa, nm, t)
 
@@ -270,7 +283,7 @@ def main():
         "metric": "accepted tokens/sec (tree speculative decode, temperature 0)", "value": round(value, 3),
         "unit": "accepted tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix "
                                f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1",
                    "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
@@ -285,7 +298,7 @@ def main():
         gs = gpool.stats()
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_gemm.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and args.model == "llama3-8b-262k" and Ls == 16384:     # the PMC pass was taken on this workload
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
@@ -304,7 +317,7 @@ def main():
         ab = algo_bytes_verify(Ls, H, Hkv)
         a_traffic = None
         tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and args.model == "llama3-8b-262k" and Ls == 16384:
             try:
                 a_traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
