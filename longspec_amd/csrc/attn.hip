@@ -1183,10 +1183,25 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     if (joint) mx = fmaxf(mx, lnew);
     const float mref = mx == -INFINITY ? 0.f : mx;
     // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
-    // o = 0) so that 4 independent 16-byte loads are in flight per thread
+    // o = 0) so that 8 independent 16-byte loads are in flight per thread
     float den = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     int i = 0;
+    for (; i + 8 <= p.n_parts; i += 8) {
+        float l8[8];
+        f32x4 o8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            l8[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
+            o8[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float wgt = expf(l8[u] - mref);
+            den += wgt;
+            o += o8[u] * wgt;
+        }
+    }
     for (; i + 4 <= p.n_parts; i += 4) {
         float l4[4];
         f32x4 o4[4];
