@@ -297,6 +297,21 @@ def test_verify_attention_model_shapes_vs_oracle(ops, H, Hkv):
         assert torch.equal(kc_g.cpu(), kc_r)
 
 
+@pytest.mark.parametrize("L", [0, 1, 31, 32, 33, 63, 65, 130])
+def test_verify_attention_empty_and_tiny_prefix(ops, L):
+    """Edge lengths of the warp-specialised path (Llama-3 heads): no prefix at all, one key, one key short of /
+    one key past a 32-key block and a 64-key tile, with a grid sized for a much longer cache (empty splits)."""
+    H, Hkv = 32, 8
+    q, k, v, kc, vc, tm = toy.verify_inputs(H, Hkv, L, 90 + L, a=3)
+    cl = torch.tensor([L], dtype=torch.int32)
+    kc_r, vc_r = kc.clone(), vc.clone()
+    ref = ref_ops.target_verify_attention(q, k, v, kc_r, vc_r, cl, tm, False)
+    kc_g, vc_g = g(kc), g(vc)
+    out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), False, kv_len_hint=L + 2000)
+    assert_close_f16(out, ref, atol=2.1e-3, what=f"L={L}")
+    assert torch.equal(kc_g.cpu(), kc_r)
+
+
 # --------------------------------------------------------------------------- #
 # draft self-attention chain (step 0 + 4 tree levels on one cache)
 # --------------------------------------------------------------------------- #

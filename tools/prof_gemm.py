@@ -14,17 +14,19 @@ ap.add_argument("--calls", type=int, default=6)
 ap.add_argument("--splits", type=int, default=0)
 ap.add_argument("--silu", action="store_true")
 ap.add_argument("--no-torch", action="store_true")
+ap.add_argument("--copies", type=int, default=4, help="1 = the same weight every call (served by the 256 MB Infinity Cache)")
 a = ap.parse_args()
 g = torch.Generator(device="cpu").manual_seed(0)
 Ws = [(torch.randn(a.N, a.K, generator=g) * 0.02).half().cuda() for _ in range(4)]
+NC = max(1, min(4, a.copies))
 x = torch.randn(a.M, a.K, generator=g).half().cuda()
 PW = [ops.pack_weight(w) for w in Ws]
 PGU = [ops.pack_gate_up(Ws[i], Ws[(i + 1) % 4]) for i in range(4)] if a.silu else None
 for i in range(a.calls):
     if a.silu:
-        ops.mlp_gate_up(x, PGU[i % 4], n_splits=a.splits)
+        ops.mlp_gate_up(x, PGU[i % NC], n_splits=a.splits)
     else:
-        ops.linear(x, PW[i % 4], n_splits=a.splits)
+        ops.linear(x, PW[i % NC], n_splits=a.splits)
     if not a.no_torch:
         torch.nn.functional.linear(x, Ws[i % 4])
 torch.cuda.synchronize()
