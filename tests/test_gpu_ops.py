@@ -312,6 +312,25 @@ def test_verify_attention_empty_and_tiny_prefix(ops, L):
     assert torch.equal(kc_g.cpu(), kc_r)
 
 
+@pytest.mark.parametrize("H,Hkv,sq", [(32, 8, 74), (8, 2, 16), (4, 4, 74)])
+def test_prefix_with_late_dominant_keys(ops, H, Hkv, sq):
+    """The streaming loops fix the soft-max reference from a split's FIRST keys; keys that later outscore it by
+    more than fp16 can hold (> e^11) must trigger the rerun with the true row maxima, not an overflow.  Keys
+    1500..1503 are 24x a query direction: scores ~ +270 where everything before is ~ N(0,1)."""
+    L = 3000
+    q = toy.randn_f16((1, sq, H, 128), 401)
+    kc, vc = _mk_cache(H, Hkv, L, 402)
+    for h in range(Hkv):
+        kc[0, 1500:1504, h] = (q[0, 0, h * (H // Hkv)].float() * 24).half()
+    cl = torch.tensor([L], dtype=torch.int32)
+    o_ref, lse_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True)
+    for n_splits in (0, 1, 3):
+        o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), return_softmax_lse=True, kv_len_hint=L,
+                                       n_splits=n_splits)
+        assert_close_f16(o, o_ref, atol=2.1e-3, what=f"late keys, splits={n_splits}")
+        assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-4
+
+
 # --------------------------------------------------------------------------- #
 # draft self-attention chain (step 0 + 4 tree levels on one cache)
 # --------------------------------------------------------------------------- #
