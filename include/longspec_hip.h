@@ -210,19 +210,56 @@ int ls_logprob_topk(const void* logits, int rows, int vocab, int64_t ld, int dty
 int ls_argmax_rows(const void* logits, int rows, int vocab, int64_t ld, int dtype, int64_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- accept / reject tree collapse (K10) ---------------------------------------- */
+/* ---- beam-tree bookkeeping of a round (K10) ----------------------------------------------
+ * The reference spells these steps as a few dozen tiny tensor ops per round
+ * (longspec/test/llama_glide.py:1019-1121); each is one launch here, one workgroup per batch row. */
 
-/* LlamaGlide.tree_verification (longspec/test/llama_glide.py:1128-1175), b == 1 per call
- * row: all_spec/all_llm_pred [b,F] int64, tree_mask [b,F,F] int64, cache_lens [b] int32
- * (already advanced by acc-1, :1104).  Outputs: acc_ids [b,max_acc] int64 (padded with
- * all_llm_pred entries exactly like the reference's gather), acc_num [b] int64,
- * double_input [b] int32, index_mapping [b,max_acc] int64.  Moves the LAST target layer's
- * KV rows cache_lens+index_mapping[j] -> cache_lens+j (j < acc_num) in the same launch. */
+/* One more tree level (llama_glide.py:1021-1027 for the root's children, :1056-1075 deeper): new node
+ * mid+j (j < k) is the child of node  lo + topk_idx[j] / vocab  and carries token  topk_idx[j] % vocab:
+ *   all_spec[mid+j] = token;  logp_sum[mid+j] = topk_vals[j];
+ *   tree_mask[mid+j, :] = tree_mask[father, :] + I[mid+j, :]          (the gather + diag_one of :1066-1067)
+ * tree_mask [b,F,F] int64, all_spec [b,F] int64, logp_sum [b,F] fp32, topk_vals [b,k] fp32, topk_idx [b,k] int64.
+ * positions [b,k] int64 / bits [b,k,words] (both or neither): what ls_tree_positions / ls_pack_tree_mask give
+ * on tree_mask[mid:mid+k, :mid+k] for the draft pass over the new level, with base + base_add as the cache
+ * length.  base [b] int32 (nullable) is advanced by base_add in place (`draft_cache_lens += acc - 1`, :1027). */
+int ls_tree_grow(int64_t* tree_mask, int64_t* all_spec, float* logp_sum, const float* topk_vals,
+                 const int64_t* topk_idx, int b, int F, int k, int64_t vocab, int lo, int mid,
+                 int32_t* base, int base_add, int64_t* positions, uint32_t* bits, int words, void* stream);
+
+/* Inputs of the verification pass (llama_glide.py:1078-1086).  R rows = [a accepted | F-1 tree nodes | pads]:
+ *   veri_spec [b,R] int64 = [acc_ids[:a], all_spec[1:], 0...]        (acc_ids row stride acc_stride)
+ *   mask = tril(ones(R,R)); mask[a:a+F-1, a:a+F-1] = tree_mask[1:,1:]; mask = tril(mask)
+ *   positions [b,R] int64 = cache_lens + mask.sum(-1) - 1 (llama.py:575-577); bits [b,R,words] = mask != 0.
+ * bump [b] int32 (nullable) += bump_add: the `draft_cache_lens += 1` of :1076. */
+int ls_tree_verify_inputs(const int64_t* acc_ids, int64_t acc_stride, int a, const int64_t* all_spec,
+                          const int64_t* tree_mask, int b, int F, int R, const int32_t* cache_lens,
+                          int64_t* veri_spec, int64_t* positions, uint32_t* bits, int words,
+                          int32_t* bump, int bump_add, void* stream);
+
+/* LlamaGlide.tree_verification (longspec/test/llama_glide.py:1128-1175): all_spec/all_llm_pred [b,F]
+ * int64, tree_mask [b,F,F] int64 (entries >= 0), cache_lens [b] int32 (+ cache_len_add = the `acc - 1`
+ * of :1104).  Outputs: acc_ids [b,max_acc] int64 zero-padded, acc_num [b] int64, double_input [b] int32,
+ * index_mapping [b,max_acc] int64 (-1 padded).  Moves the LAST target layer's KV rows
+ * len+index_mapping[j] -> len+j (j < acc_num) in the same launch (k_cache NULL: no move). */
 int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const int64_t* tree_mask,
-                     const int32_t* cache_lens, int b, int F, int non_leaf_len, int max_acc,
+                     const int32_t* cache_lens, int cache_len_add, int b, int F, int non_leaf_len, int max_acc,
                      int64_t* acc_ids, int64_t* acc_num, int32_t* double_input, int64_t* index_mapping,
                      void* k_cache, void* v_cache, int64_t kc_stride_b, int64_t kc_stride_s,
                      int row_elems, int dtype, void* stream);
+
+/* End of the round (llama_glide.py:1093-1121): output_ids[z, emitted + j] = acc_ids[z, j] (j < acc_num);
+ * state[z] = (acc_num, any(output_ids[z, :out_cap] == eos)) for the round's single host read; the tree
+ * state reset (tree_mask = 0, column 0 = 1; all_spec = 0, all_spec[0] = last accepted id; logp_sum = 0);
+ * target_lens [b] int32 += target_add and draft_kv_lens [b] int32 += acc_num (both nullable). */
+int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int max_acc, int64_t* output_ids,
+                   int64_t out_stride, int out_cap, int emitted, int has_eos, int64_t eos, int64_t* state,
+                   int64_t* tree_mask, int64_t* all_spec, float* logp_sum, int F, int32_t* target_lens,
+                   int target_add, int32_t* draft_kv_lens, void* stream);
+
+/* `embed_tokens(ids)` of a short pass (llama.py:579, llama_glide.py:1003,1030): out [n,hidden] =
+ * table[ids] (table [vocab,hidden] dtype, ids int64 inside the vocabulary). */
+int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int n,
+                  void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-// Latency-bound operators of the decode round: RMSNorm, RoPE, tree positions and the
-// accept/reject tree collapse.  KB-scale traffic each: single-pass kernels, vectorised
+// Latency-bound operators of the decode round: RMSNorm, RoPE and tree positions (the beam-tree
+// bookkeeping kernels live in tree.hip).  KB-scale traffic each: single-pass kernels, vectorised
 // 16-byte accesses, no host synchronisation.
 #include <stdarg.h>
 
@@ -127,117 +127,6 @@ __global__ void tree_positions_kernel(const int64_t* __restrict__ mask, const in
     if (lane == 0) pos[row] = s - 1 + (base ? (long)base[row / M] : 0);
 }
 
-// ---- accept / reject tree collapse ------------------------------------------------------
-// LlamaGlide.tree_verification (llama_glide.py:1128-1175).  One workgroup per batch row.
-constexpr int MAXF = 1024;
-__global__ __launch_bounds__(256) void tree_collapse_kernel(
-    const int64_t* __restrict__ all_spec, const int64_t* __restrict__ all_pred, const int64_t* __restrict__ tree_mask,
-    const int32_t* __restrict__ cache_lens, int Fn, int non_leaf_len, int max_acc, int64_t* __restrict__ acc_ids,
-    int64_t* __restrict__ acc_num, int32_t* __restrict__ double_input, int64_t* __restrict__ index_mapping, char* k_cache,
-    char* v_cache, long kc_sb_bytes, long kc_ss_bytes, int row_bytes) {
-    __shared__ int father[MAXF];
-    __shared__ unsigned char verify[MAXF];
-    __shared__ int s_last;
-    __shared__ int s_count;
-    __shared__ int s_map[MAXF];
-    const int z = blockIdx.x, tid = threadIdx.x;
-    const int64_t* spec = all_spec + (long)z * Fn;
-    const int64_t* pred = all_pred + (long)z * Fn;
-    const int64_t* mask = tree_mask + (long)z * Fn * Fn;
-    if (tid == 0) {
-        s_last = 0;
-        s_count = 0;
-    }
-    // father[r] = argmax_c((mask - I)[r,c] * c): the largest c != r with mask[r,c] != 0, else 0 (:1136)
-    for (int r = tid; r < Fn; r += 256) {
-        long best = 0;
-        int bi = 0;
-        for (int c = 0; c < Fn; ++c) {
-            const long v = (mask[(long)r * Fn + c] - (r == c ? 1 : 0)) * (long)c;
-            if (v > best) {
-                best = v;
-                bi = c;
-            }
-        }
-        father[r] = bi;
-    }
-    __syncthreads();
-    for (int r = tid; r < Fn; r += 256) verify[r] = (r == 0) || (pred[father[r]] == spec[r]);   // :1138-1139
-    __syncthreads();
-    // final[r] = sum_c mask[r,c]*verify[c] == sum_c mask[r,c]; last = argmax_r(final[r]*r)   (:1140-1144)
-    for (int r = tid; r < Fn; r += 256) {
-        long a = 0, t = 0;
-        for (int c = 0; c < Fn; ++c) {
-            const long mv = mask[(long)r * Fn + c];
-            a += mv * (long)verify[c];
-            t += mv;
-        }
-        if (a == t && r > 0) atomicMax(&s_last, r);
-    }
-    __syncthreads();
-    const int last = s_last;
-    // selected columns of mask[last] in ascending order (:1147-1154)
-    if (tid < 64) {
-        int base = 0;
-        for (int c0 = 0; c0 < Fn; c0 += 64) {
-            const int c = c0 + tid;
-            const bool sel = (c < Fn) && (mask[(long)last * Fn + c] != 0);
-            const unsigned long long bal = __ballot(sel);
-            if (sel) {
-                const int rank = base + __popcll(bal & ((1ull << tid) - 1ull));
-                s_map[rank] = c;
-            }
-            base += __popcll(bal);
-        }
-        if (tid == 0) s_count = base;
-    }
-    __syncthreads();
-    const int n_acc = s_count;
-    if (tid == 0) {
-        acc_num[z] = n_acc;
-        double_input[z] = last >= non_leaf_len ? 1 : 0;
-    }
-    for (int j = tid; j < max_acc; j += 256) {
-        const int src = j < n_acc ? s_map[j] : -1;
-        index_mapping[(long)z * max_acc + j] = src;
-        acc_ids[(long)z * max_acc + j] = src >= 0 ? pred[src] : 0;       // :1155
-    }
-    // move the last target layer's KV rows cache_lens + map[j] -> cache_lens + j   (:1159-1173)
-    if (k_cache == nullptr) return;
-    const long L = cache_lens[z];
-    const int chunks_per_row = row_bytes / 16;
-    const int n_move = min(n_acc, max_acc);
-    const int total = n_move * chunks_per_row;
-    constexpr int MAXC = 8;                                 // 16-byte chunks per thread and tensor in flight
-    for (int c0 = 0; c0 < total; c0 += 256 * MAXC) {
-        uint4 kb[MAXC], vb[MAXC];
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int idx = c0 + i * 256 + tid;
-            if (idx < total) {
-                const int j = idx / chunks_per_row, ch = idx % chunks_per_row;
-                const long src = (long)z * kc_sb_bytes + (L + s_map[j]) * kc_ss_bytes + (long)ch * 16;
-                kb[i] = *reinterpret_cast<const uint4*>(k_cache + src);
-                vb[i] = *reinterpret_cast<const uint4*>(v_cache + src);
-            }
-        }
-        // rows are moved towards lower indices (map[j] >= j): a chunk group never overwrites a
-        // source row of a LATER group only if every read of this group finished first
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int idx = c0 + i * 256 + tid;
-            if (idx < total) {
-                const int j = idx / chunks_per_row, ch = idx % chunks_per_row;
-                const long dst = (long)z * kc_sb_bytes + (L + j) * kc_ss_bytes + (long)ch * 16;
-                *reinterpret_cast<uint4*>(k_cache + dst) = kb[i];
-                *reinterpret_cast<uint4*>(v_cache + dst) = vb[i];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -305,26 +194,6 @@ int ls_tree_positions(const int64_t* tree_mask, const int32_t* base, int b, int 
     hipLaunchKernelGGL(tree_positions_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
                        tree_mask, base, M, N, positions, rows);
     LS_CHECK_LAUNCH("tree_positions_kernel");
-    return LS_OK;
-}
-
-int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const int64_t* tree_mask,
-                     const int32_t* cache_lens, int b, int F, int non_leaf_len, int max_acc, int64_t* acc_ids,
-                     int64_t* acc_num, int32_t* double_input, int64_t* index_mapping, void* k_cache, void* v_cache,
-                     int64_t kc_stride_b, int64_t kc_stride_s, int row_elems, int dtype, void* stream) {
-    if (!all_spec || !all_llm_pred || !tree_mask || !acc_ids || !acc_num || !double_input || !index_mapping)
-        LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: null pointer");
-    if (b < 1 || F < 1 || F > MAXF || max_acc < 1 || max_acc > F) LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: F=%d max_acc=%d", F, max_acc);
-    if (k_cache) {
-        if (!v_cache || !cache_lens || row_elems < 8 || (row_elems & 7) || (kc_stride_s & 7))
-            LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: KV move args");
-        if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
-    }
-    hipLaunchKernelGGL(tree_collapse_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(stream), all_spec,
-                       all_llm_pred, tree_mask, cache_lens, F, non_leaf_len, max_acc, acc_ids, acc_num, double_input,
-                       index_mapping, (char*)k_cache, (char*)v_cache, (long)kc_stride_b * 2, (long)kc_stride_s * 2,
-                       row_elems * 2);
-    LS_CHECK_LAUNCH("tree_collapse_kernel");
     return LS_OK;
 }
 

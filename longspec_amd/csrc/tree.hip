@@ -1,0 +1,342 @@
+// Beam-tree bookkeeping of the draft-then-verify round: growing the tree by one level, assembling the
+// verification pass's inputs, the accept/reject collapse, the end-of-round commit, and the token-embedding
+// gather of the <= 80-row passes.  All of it is KB-scale integer work that the reference spells as a few dozen
+// tiny tensor ops per round (llama_glide.py:1019-1121); here each step is ONE launch of one workgroup per batch
+// row, every global load of a step issued before the first dependent use (these kernels are pure latency).
+#include "ls_common.h"
+
+namespace {
+
+constexpr int MAXF = 1024;      // tree nodes
+constexpr int TT = 1024;        // threads per workgroup (16 waves)
+
+__device__ __forceinline__ long wave_sum_i64(long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- one more tree level (llama_glide.py:1021-1027 for the root's children, :1056-1075 deeper) ---------------
+// wave w creates node mid + w (+16, ...): row copy of the father's mask row + the diagonal, the packed bits and the
+// position of the new node for the draft pass that runs next.
+__global__ __launch_bounds__(TT) void tree_grow_kernel(int64_t* __restrict__ tree_mask, int64_t* __restrict__ all_spec,
+                                                       float* __restrict__ logp_sum, const float* __restrict__ vals,
+                                                       const int64_t* __restrict__ idx, int F, int k, long vocab, int lo,
+                                                       int mid, int32_t* base, int base_add, int64_t* __restrict__ positions,
+                                                       uint32_t* __restrict__ bits, int words) {
+    const int z = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t* mask = tree_mask + (long)z * F * F;
+    const int hi = mid + k;
+    const long b0 = base ? (long)base[z] + base_add : 0;
+    for (int j = wave; j < k; j += TT / 64) {
+        const long t = idx[(long)z * k + j];
+        int father = (int)(t / vocab) + lo;
+        father = father < 0 ? 0 : (father >= mid ? mid - 1 : father);       // memory safety only: fathers precede `mid` by construction
+        const int row = mid + j;
+        long s = 0;
+        for (int c0 = 0; c0 < F; c0 += 64) {
+            const int c = c0 + lane;
+            long v = 0;
+            if (c < F) {
+                v = mask[(long)father * F + c] + (c == row ? 1 : 0);
+                mask[(long)row * F + c] = v;
+            }
+            if (c < hi) s += v;
+            const unsigned long long bal = __ballot(c < hi && v != 0);
+            if (bits && lane == 0) {
+                const int w = c0 >> 5;
+                uint32_t* br = bits + ((long)z * k + j) * words;
+                if (w < words) br[w] = (uint32_t)bal;
+                if (w + 1 < words) br[w + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        s = wave_sum_i64(s);
+        if (lane == 0) {
+            all_spec[(long)z * F + row] = t % vocab;
+            logp_sum[(long)z * F + row] = vals[(long)z * k + j];
+            if (positions) positions[(long)z * k + j] = b0 + s - 1;
+        }
+    }
+    __syncthreads();                                   // every wave has read base[z]
+    if (threadIdx.x == 0 && base && base_add) base[z] += base_add;
+}
+
+// ---- inputs of the verification pass (llama_glide.py:1078-1086) -----------------------------------------------
+// R rows = [a accepted tokens | F-1 tree nodes | pads]; mask = tril(ones); mask[a:a+F-1, a:a+F-1] = tree_mask[1:,1:];
+// mask = tril(mask).  Emits the token ids, the packed mask and the positions (mask.sum(-1) - 1 + cache_lens).
+__global__ __launch_bounds__(TT) void tree_verify_inputs_kernel(const int64_t* __restrict__ acc_ids, long acc_stride, int a,
+                                                                const int64_t* __restrict__ all_spec,
+                                                                const int64_t* __restrict__ tree_mask, int F, int R,
+                                                                const int32_t* __restrict__ cache_lens,
+                                                                int64_t* __restrict__ veri_spec, int64_t* __restrict__ positions,
+                                                                uint32_t* __restrict__ bits, int words, int32_t* bump,
+                                                                int bump_add) {
+    const int z = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t* mask = tree_mask + (long)z * F * F;
+    const long L = cache_lens ? (long)cache_lens[z] : 0;
+    const int t_end = a + F - 1;                       // first pad row
+    for (int i = wave; i < R; i += TT / 64) {
+        const bool tree_row = i >= a && i < t_end;
+        long s = 0;
+        for (int c0 = 0; c0 < R; c0 += 64) {
+            const int c = c0 + lane;
+            long v = 0;
+            if (c < R && c <= i) v = (tree_row && c >= a) ? mask[(long)(i - a + 1) * F + (c - a + 1)] : 1;
+            s += v;
+            const unsigned long long bal = __ballot(v != 0);
+            if (lane == 0) {
+                const int w = c0 >> 5;
+                uint32_t* br = bits + ((long)z * R + i) * words;
+                if (w < words) br[w] = (uint32_t)bal;
+                if (w + 1 < words) br[w + 1] = (uint32_t)(bal >> 32);
+            }
+        }
+        s = wave_sum_i64(s);
+        if (lane == 0) {
+            positions[(long)z * R + i] = L + s - 1;
+            veri_spec[(long)z * R + i] = i < a ? acc_ids[(long)z * acc_stride + i] : (i < t_end ? all_spec[(long)z * F + i - a + 1] : 0);
+        }
+    }
+    if (threadIdx.x == 0 && bump && bump_add) bump[z] += bump_add;       // not read by this kernel
+}
+
+// ---- accept / reject tree collapse (LlamaGlide.tree_verification, llama_glide.py:1128-1175) --------------------
+__global__ __launch_bounds__(TT) void tree_collapse_kernel(
+    const int64_t* __restrict__ all_spec, const int64_t* __restrict__ all_pred, const int64_t* __restrict__ tree_mask,
+    const int32_t* __restrict__ cache_lens, int len_add, int Fn, int non_leaf_len, int max_acc, int64_t* __restrict__ acc_ids,
+    int64_t* __restrict__ acc_num, int32_t* __restrict__ double_input, int64_t* __restrict__ index_mapping, char* k_cache,
+    char* v_cache, long kc_sb_bytes, long kc_ss_bytes, int row_bytes) {
+    __shared__ unsigned long long best[MAXF];           // (mask*c) << 10 | (1023 - c): argmax with first-index ties
+    __shared__ unsigned long long tsum[MAXF];
+    __shared__ unsigned long long asum[MAXF];
+    __shared__ int s_map[MAXF];
+    __shared__ unsigned char verify[MAXF];
+    __shared__ int s_last;
+    __shared__ int s_count;
+    const int z = blockIdx.x, tid = threadIdx.x;
+    const int64_t* spec = all_spec + (long)z * Fn;
+    const int64_t* pred = all_pred + (long)z * Fn;
+    const int64_t* mask = tree_mask + (long)z * Fn * Fn;
+    for (int r = tid; r < Fn; r += TT) {
+        best[r] = 0;
+        tsum[r] = 0;
+        asum[r] = 0;
+    }
+    if (tid == 0) {
+        s_last = 0;
+        s_count = 0;
+    }
+    __syncthreads();
+    // father[r] = argmax_c((mask - I)[r,c] * c): the largest mask*c over c != r, first c on ties, 0 if none (:1136);
+    // tsum[r] = sum_c mask[r,c]
+    const int total = Fn * Fn;
+#pragma unroll 4
+    for (int i = tid; i < total; i += TT) {
+        const long m = mask[i];
+        const int r = i / Fn, c = i - r * Fn;
+        const long v = c == r ? (m - 1) * (long)c : m * (long)c;
+        if (v > 0) atomicMax(&best[r], ((unsigned long long)v << 10) | (unsigned long long)(1023 - c));
+        if (m != 0) atomicAdd(&tsum[r], (unsigned long long)m);
+    }
+    __syncthreads();
+    for (int r = tid; r < Fn; r += TT) {
+        const int father = best[r] ? 1023 - (int)(best[r] & 1023) : 0;
+        verify[r] = (r == 0) || (pred[father] == spec[r]);                                   // :1138-1139
+    }
+    __syncthreads();
+    // final[r] = sum_c mask[r,c]*verify[c] == sum_c mask[r,c]; last = argmax_r(final[r]*r)   (:1140-1144)
+#pragma unroll 4
+    for (int i = tid; i < total; i += TT) {
+        const long m = mask[i];
+        const int r = i / Fn, c = i - r * Fn;
+        if (m != 0 && verify[c]) atomicAdd(&asum[r], (unsigned long long)m);
+    }
+    __syncthreads();
+    for (int r = tid; r < Fn; r += TT)
+        if (r > 0 && asum[r] == tsum[r]) atomicMax(&s_last, r);
+    __syncthreads();
+    const int last = s_last;
+    // selected columns of mask[last] in ascending order (:1147-1154)
+    if (tid < 64) {
+        int base = 0;
+        for (int c0 = 0; c0 < Fn; c0 += 64) {
+            const int c = c0 + tid;
+            const bool sel = (c < Fn) && (mask[(long)last * Fn + c] != 0);
+            const unsigned long long bal = __ballot(sel);
+            if (sel) s_map[base + __popcll(bal & ((1ull << tid) - 1ull))] = c;
+            base += __popcll(bal);
+        }
+        if (tid == 0) s_count = base;
+    }
+    __syncthreads();
+    const int n_acc = s_count;
+    if (tid == 0) {
+        acc_num[z] = n_acc;
+        double_input[z] = last >= non_leaf_len ? 1 : 0;
+    }
+    for (int j = tid; j < max_acc; j += TT) {
+        const int src = j < n_acc ? s_map[j] : -1;
+        index_mapping[(long)z * max_acc + j] = src;
+        acc_ids[(long)z * max_acc + j] = src >= 0 ? pred[src] : 0;       // :1155
+    }
+    // move the last target layer's KV rows L + map[j] -> L + j   (:1159-1173)
+    if (k_cache == nullptr) return;
+    const long L = (long)cache_lens[z] + len_add;
+    const int chunks_per_row = row_bytes / 16;
+    const int n_move = min(n_acc, max_acc);
+    const int total_ch = n_move * chunks_per_row;
+    constexpr int MAXC = 2;                                 // 16-byte chunks per thread and tensor in flight
+    for (int c0 = 0; c0 < total_ch; c0 += TT * MAXC) {
+        uint4 kb[MAXC], vb[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ix = c0 + i * TT + tid;
+            if (ix < total_ch) {
+                const int j = ix / chunks_per_row, ch = ix % chunks_per_row;
+                const long src = (long)z * kc_sb_bytes + (L + s_map[j]) * kc_ss_bytes + (long)ch * 16;
+                kb[i] = *reinterpret_cast<const uint4*>(k_cache + src);
+                vb[i] = *reinterpret_cast<const uint4*>(v_cache + src);
+            }
+        }
+        // rows move towards lower indices (map[j] >= j): a group may only be written once every read of it is done
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ix = c0 + i * TT + tid;
+            if (ix < total_ch) {
+                const int j = ix / chunks_per_row, ch = ix % chunks_per_row;
+                const long dst = (long)z * kc_sb_bytes + (L + j) * kc_ss_bytes + (long)ch * 16;
+                *reinterpret_cast<uint4*>(k_cache + dst) = kb[i];
+                *reinterpret_cast<uint4*>(v_cache + dst) = vb[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- end of the round (llama_glide.py:1093-1121) ----------------------------------------------------------------
+// emitted tokens -> output_ids, the whole-buffer EOS test (:1120), the reset of the tree state for the next round
+// (:1098-1102) and the length bookkeeping (:1104-1117), behind ONE host read of state[z] = (acc_num, eos hit).
+__global__ __launch_bounds__(TT) void tree_commit_kernel(const int64_t* __restrict__ acc_ids, const int64_t* __restrict__ acc_num,
+                                                         int max_acc, int64_t* __restrict__ output_ids, long out_stride,
+                                                         int out_cap, int emitted, int has_eos, int64_t eos,
+                                                         int64_t* __restrict__ state, int64_t* __restrict__ tree_mask,
+                                                         int64_t* __restrict__ all_spec, float* __restrict__ logp_sum, int F,
+                                                         int32_t* target_lens, int target_add, int32_t* draft_kv_lens) {
+    __shared__ int s_hit;
+    const int z = blockIdx.x, tid = threadIdx.x;
+    const int n = (int)acc_num[z];
+    int64_t* out = output_ids + (long)z * out_stride;
+    if (tid == 0) s_hit = 0;
+    if (tid < max_acc && tid < n && emitted + tid < out_cap) out[emitted + tid] = acc_ids[(long)z * max_acc + tid];
+    const int64_t next_root = n >= 1 ? acc_ids[(long)z * max_acc + min(n, max_acc) - 1] : 0;
+    __syncthreads();
+    if (has_eos) {
+        int hit = 0;
+        for (int i = tid; i < out_cap; i += TT) hit |= out[i] == eos;
+        if (hit) atomicOr(&s_hit, 1);
+    }
+    int64_t* mask = tree_mask + (long)z * F * F;
+    for (int i = tid; i < F * F; i += TT) mask[i] = (i % F) == 0 ? 1 : 0;
+    for (int i = tid; i < F; i += TT) {
+        all_spec[(long)z * F + i] = i == 0 ? next_root : 0;
+        if (logp_sum) logp_sum[(long)z * F + i] = 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        state[2 * z] = n;
+        state[2 * z + 1] = s_hit;
+        if (target_lens) target_lens[z] += target_add;
+        if (draft_kv_lens) draft_kv_lens[z] += n;
+    }
+}
+
+// ---- token embedding of a short pass: out[i,:] = table[ids[i],:] ----------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const char* __restrict__ table, const int64_t* __restrict__ ids,
+                                                         long vocab, int row_bytes, char* __restrict__ out) {
+    long id = ids[blockIdx.x];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // memory safety; ids come from `% vocab` / argmax
+    const char* src = table + id * (long)row_bytes;
+    char* dst = out + (long)blockIdx.x * row_bytes;
+    for (int o = threadIdx.x * 16; o < row_bytes; o += 256 * 16)
+        *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ls_tree_grow(int64_t* tree_mask, int64_t* all_spec, float* logp_sum, const float* topk_vals, const int64_t* topk_idx,
+                 int b, int F, int k, int64_t vocab, int lo, int mid, int32_t* base, int base_add, int64_t* positions,
+                 uint32_t* bits, int words, void* stream) {
+    if (!tree_mask || !all_spec || !logp_sum || !topk_vals || !topk_idx) LS_FAIL(LS_ERR_INVALID_ARG, "tree_grow: null pointer");
+    if (b < 1 || F < 2 || F > MAXF || k < 1 || vocab < 1 || lo < 0 || mid <= lo || mid + k > F)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_grow: F=%d k=%d lo=%d mid=%d", F, k, lo, mid);
+    if ((positions == nullptr) != (bits == nullptr)) LS_FAIL(LS_ERR_INVALID_ARG, "tree_grow: positions and bits go together");
+    if (bits && words * 32 < mid + k) LS_FAIL(LS_ERR_INVALID_ARG, "tree_grow: %d words for %d columns", words, mid + k);
+    hipLaunchKernelGGL(tree_grow_kernel, dim3(b), dim3(TT), 0, static_cast<hipStream_t>(stream), tree_mask, all_spec, logp_sum,
+                       topk_vals, topk_idx, F, k, (long)vocab, lo, mid, base, base_add, positions, bits, words);
+    LS_CHECK_LAUNCH("tree_grow_kernel");
+    return LS_OK;
+}
+
+int ls_tree_verify_inputs(const int64_t* acc_ids, int64_t acc_stride, int a, const int64_t* all_spec, const int64_t* tree_mask,
+                          int b, int F, int R, const int32_t* cache_lens, int64_t* veri_spec, int64_t* positions, uint32_t* bits,
+                          int words, int32_t* bump, int bump_add, void* stream) {
+    if (!acc_ids || !all_spec || !tree_mask || !veri_spec || !positions || !bits)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_verify_inputs: null pointer");
+    if (b < 1 || F < 1 || F > MAXF || a < 1 || R < a + F - 1 || words * 32 < R)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_verify_inputs: a=%d F=%d R=%d words=%d", a, F, R, words);
+    hipLaunchKernelGGL(tree_verify_inputs_kernel, dim3(b), dim3(TT), 0, static_cast<hipStream_t>(stream), acc_ids,
+                       (long)acc_stride, a, all_spec, tree_mask, F, R, cache_lens, veri_spec, positions, bits, words, bump,
+                       bump_add);
+    LS_CHECK_LAUNCH("tree_verify_inputs_kernel");
+    return LS_OK;
+}
+
+int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const int64_t* tree_mask,
+                     const int32_t* cache_lens, int cache_len_add, int b, int F, int non_leaf_len, int max_acc,
+                     int64_t* acc_ids, int64_t* acc_num, int32_t* double_input, int64_t* index_mapping, void* k_cache,
+                     void* v_cache, int64_t kc_stride_b, int64_t kc_stride_s, int row_elems, int dtype, void* stream) {
+    if (!all_spec || !all_llm_pred || !tree_mask || !acc_ids || !acc_num || !double_input || !index_mapping)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: null pointer");
+    if (b < 1 || F < 1 || F > MAXF || max_acc < 1 || max_acc > F) LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: F=%d max_acc=%d", F, max_acc);
+    if (k_cache) {
+        if (!v_cache || !cache_lens || row_elems < 8 || (row_elems & 7) || (kc_stride_s & 7))
+            LS_FAIL(LS_ERR_INVALID_ARG, "tree_collapse: KV move args");
+        if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
+    }
+    hipLaunchKernelGGL(tree_collapse_kernel, dim3(b), dim3(TT), 0, static_cast<hipStream_t>(stream), all_spec, all_llm_pred,
+                       tree_mask, cache_lens, cache_len_add, F, non_leaf_len, max_acc, acc_ids, acc_num, double_input,
+                       index_mapping, (char*)k_cache, (char*)v_cache, (long)kc_stride_b * 2, (long)kc_stride_s * 2,
+                       row_elems * 2);
+    LS_CHECK_LAUNCH("tree_collapse_kernel");
+    return LS_OK;
+}
+
+int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int max_acc, int64_t* output_ids,
+                   int64_t out_stride, int out_cap, int emitted, int has_eos, int64_t eos, int64_t* state, int64_t* tree_mask,
+                   int64_t* all_spec, float* logp_sum, int F, int32_t* target_lens, int target_add, int32_t* draft_kv_lens,
+                   void* stream) {
+    if (!acc_ids || !acc_num || !output_ids || !state || !tree_mask || !all_spec)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_commit: null pointer");
+    if (b < 1 || F < 1 || F > MAXF || max_acc < 1 || max_acc > TT || out_cap < 1 || emitted < 0)
+        LS_FAIL(LS_ERR_INVALID_ARG, "tree_commit: F=%d max_acc=%d out_cap=%d emitted=%d", F, max_acc, out_cap, emitted);
+    hipLaunchKernelGGL(tree_commit_kernel, dim3(b), dim3(TT), 0, static_cast<hipStream_t>(stream), acc_ids, acc_num, max_acc,
+                       output_ids, (long)out_stride, out_cap, emitted, has_eos, eos, state, tree_mask, all_spec, logp_sum, F,
+                       target_lens, target_add, draft_kv_lens);
+    LS_CHECK_LAUNCH("tree_commit_kernel");
+    return LS_OK;
+}
+
+int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int n, void* out, void* stream) {
+    if (!table || !ids || !out || vocab < 1 || hidden < 8 || (hidden & 7)) LS_FAIL(LS_ERR_INVALID_ARG, "embed_rows args");
+    if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
+    if (n < 1) return LS_OK;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), (const char*)table, ids,
+                       (long)vocab, hidden * 2, (char*)out);
+    LS_CHECK_LAUNCH("embed_rows_kernel");
+    return LS_OK;
+}
+
+}  // extern "C"

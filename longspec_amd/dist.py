@@ -31,12 +31,25 @@ class KVShard:
         self.is_tail = rank == world - 1
         self._send = {}
         self._recv = {}
+        self._pass_len = {}
 
     # ---- lengths ---------------------------------------------------------------------------------
     def local_len(self, global_len: torch.Tensor) -> torch.Tensor:
         """Valid prefix rows this rank attends: clamp(global - start, 0, Ls) (unbounded on the tail rank)."""
         l = (global_len.to(torch.int32) - self.start).clamp_(min=0)
         return l if self.is_tail else l.clamp_(max=self.Ls)
+
+    def begin_pass(self):
+        """A model pass starts: the length tensors do not change until it ends, so every layer of the pass shares
+        one ``local_len`` result (3 tiny kernels otherwise, per layer)."""
+        self._pass_len = {}
+
+    def pass_len(self, global_len: torch.Tensor) -> torch.Tensor:
+        hit = self._pass_len.get(global_len.data_ptr())
+        if hit is None or hit[0] is not global_len:
+            hit = (global_len, self.local_len(global_len))       # holds the key tensor: its address cannot be reused
+            self._pass_len[global_len.data_ptr()] = hit
+        return hit[1]
 
     def local_hint(self, global_hint: Optional[int]) -> Optional[int]:
         if global_hint is None:

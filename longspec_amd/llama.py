@@ -110,6 +110,20 @@ class DecodeLinear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
+class DecodeEmbedding(nn.Embedding):
+    """``nn.Embedding`` (same parameter, same state_dict key).  The token rows of a draft / verify / vanilla
+    pass are gathered by ``ops.embed_rows``; prefill-sized inputs use the library kernel."""
+
+    def __init__(self, num_embeddings, embedding_dim, ops=None):
+        super().__init__(num_embeddings, embedding_dim)
+        self.ops = ops
+
+    def forward(self, input_ids):
+        if self.ops is not None and self.ops.embed_supported(input_ids, self.weight):
+            return self.ops.embed_rows(self.weight, input_ids)
+        return F.embedding(input_ids, self.weight)
+
+
 class LlamaMLP(nn.Module):
     """``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` (transformers LlamaMLP; vendored qwen2.py:218-230).
     Decode-shaped calls run gate|up + SiLU + product as ONE weight-streaming launch."""
@@ -261,7 +275,7 @@ class LlamaAttention(nn.Module):
             if self.shard is not None:
                 sh = self.shard
                 extra = {"timing": self.timing()} if self.timing is not None else {}
-                call = self.ops.sharded_verify_attention(q, k, v, self.K_Cache, self.V_Cache, sh.local_len(cache_lens),
+                call = self.ops.sharded_verify_attention(q, k, v, self.K_Cache, self.V_Cache, sh.pass_len(cache_lens),
                                                          tree_mask_bits, self.last_layer, softmax_scale=self.softmax_scale,
                                                          kv_len_hint=sh.local_hint(self.kv_len_hint), **extra)
                 attn = sh.attend(call)
@@ -315,14 +329,18 @@ class LlamaModel(nn.Module):
         self.ops = ops
         self.padding_idx = getattr(config, "pad_token_id", None)
         self.vocab_size = config.vocab_size
-        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.embed_tokens = DecodeEmbedding(config.vocab_size, config.hidden_size, ops=ops)
         self.layers = nn.ModuleList([self.LAYER_CLS(config, i, ops=ops) for i in range(config.num_hidden_layers)])
         self.norm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
         self.rotary_emb = LlamaRotaryEmbedding(config, ops=ops)
 
     def forward(self, input_ids, position_ids=None, position_embeddings=None, inputs_embeds=None, cache_lens=None,
-                flex_attn=None, exec_type=None, tree_mask=None, induction_head=False):
-        tree_mask_bits = None
+                flex_attn=None, exec_type=None, tree_mask=None, induction_head=False, tree_mask_bits=None):
+        """``tree_mask_bits`` (with ``position_ids``) is the packed form of ``tree_mask`` from ``ops.tree_verify_inputs``;
+        given both, the dense mask is not needed."""
+        shard = getattr(self.layers[0].self_attn, "shard", None)
+        if shard is not None:
+            shard.begin_pass()
         if position_ids is None:                                    # llama.py:571-577
             if tree_mask is None:
                 position_ids = torch.arange(0, input_ids.size(1), device=input_ids.device)[None, :]
@@ -330,7 +348,7 @@ class LlamaModel(nn.Module):
                     position_ids = position_ids + cache_lens[:, None]
             else:
                 position_ids = self.ops.tree_positions(tree_mask, cache_lens)
-        if tree_mask is not None:
+        if tree_mask is not None and tree_mask_bits is None:
             tree_mask_bits = self.ops.pack_tree_mask(tree_mask)     # once per pass, shared by all layers
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)

@@ -91,7 +91,7 @@ class GlideAttention(nn.Module):
                                               kv_len_hint=self.llm_kv_len_hint)
         sh = self.shard
         # bottom-right causal alignment only matters on the rank that owns the tail of the sequence
-        call = self.ops.sharded_prefix_attention(q, K_Cache, V_Cache, sh.local_len(llm_kv_len),
+        call = self.ops.sharded_prefix_attention(q, K_Cache, V_Cache, sh.pass_len(llm_kv_len),
                                                  causal=causal and sh.is_tail, kv_len_hint=sh.local_hint(self.llm_kv_len_hint))
         return sh.attend(call)
 
@@ -152,8 +152,13 @@ class LlamaGlideDecoderLayer(nn.Module):
         self.self_attn.max_len = max_gen_len
 
     def forward(self, hidden_states, position_embeddings, llm_kv, cache_lens=None, exec_type=None, llm_kv_len=None,
-                tree_mask=None):
-        bits = self.ops.pack_tree_mask(tree_mask) if tree_mask is not None else None
+                tree_mask=None, tree_mask_bits=None):
+        """``tree_mask_bits``: the packed ``tree_mask`` when the caller already has it (``ops.tree_grow``)."""
+        bits = tree_mask_bits
+        if bits is None and tree_mask is not None:
+            bits = self.ops.pack_tree_mask(tree_mask)
+        if self.cross_attn.shard is not None:
+            self.cross_attn.shard.begin_pass()
         residual = hidden_states
         hidden_states = self.input_layernorm(hidden_states)
         hidden_states = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
@@ -440,6 +445,7 @@ class LlamaGlide(LlamaForCausalLM):
         st.output_ids = torch.full((bsz, max_gen_len), self._tree_output_fill(eos_id), dtype=torch.int64, device=dev)  # :937 (G8)
         st.spec_mask = torch.zeros((bsz, max_gen_len), dtype=torch.int64, device=dev)
         st.output_ids[:, 0] = first_token
+        cache_lens = cache_lens.to(torch.int32)              # the tree operators advance the three lengths in place
         st.cache_lens = cache_lens.clone()
         st.target_cache_lens_for_draft = cache_lens.clone()
         st.draft_cache_lens = cache_lens.clone()
@@ -451,9 +457,7 @@ class LlamaGlide(LlamaForCausalLM):
         st.emitted = 1                        # tokens written to output_ids so far
         st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
         st.tree_mask[:, :, 0] = 1
-        st.diag_one = torch.eye(Fn, dtype=torch.int64, device=dev)[None].expand(bsz, -1, -1)
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
-        st.tril = torch.tril(torch.ones((R, R), dtype=torch.int64, device=dev))
         st.eos = self._stop_id(eos_id, "tree")
         st.arange_g = torch.arange(gamma + 1, device=dev)[None, :]
         return st
@@ -461,96 +465,75 @@ class LlamaGlide(LlamaForCausalLM):
     def tree_round(self, st) -> bool:
         """One draft-then-verify round (``llama_glide.py:997-1121``): 1 + (gamma-1) draft passes growing
         the beam tree, one R-row target pass, accept/collapse.  Returns False when generation must stop.
-        The length tensors are passed without the reference's ``.clone()``: no operator here writes them, and
-        their in-place updates are ordered behind the kernels that read them on the same stream."""
+        The length tensors are passed without the reference's ``.clone()``: their in-place updates (inside
+        ``ops.tree_grow`` / ``tree_verify_inputs`` / ``tree_commit``) are ordered behind the kernels that read them on
+        the same stream."""
         cand, acc_n, Fn, gamma, R, dev, bsz = st.cand, st.acc_n, st.Fn, st.gamma, st.R, st.dev, st.bsz
-        tree_mask, all_spec, diag_one, history_logp_sum = st.tree_mask, st.all_spec, st.diag_one, st.history_logp_sum
+        tree_mask, all_spec, history_logp_sum = st.tree_mask, st.all_spec, st.history_logp_sum
         a = st.a
+        ops = self.ops
         last_attn = self.model.layers[-1].self_attn
-        history_logp_sum.zero_()
         # host bounds: no cache holds more than P + emitted (+ this round's speculative rows) valid rows
         self._set_hints(st.P + st.emitted + R, st.P + st.emitted + Fn)
         # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
         hidden_states = self.model.embed_tokens(st.acc_ids)
-        position_ids = torch.arange(0, a, device=dev)[None, :] + st.draft_cache_lens[:, None]
+        position_ids = st.arange_g[:, :a] + st.draft_cache_lens[:, None]
         position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                    llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
                                    llm_kv_len=st.target_cache_lens_for_draft, exec_type="decoding")
-        st.draft_cache_lens += a - 1
         # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits
         logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
         vocab_size = logits.size(-1)
-        topk_logp, pred_ids = self.ops.logprob_topk(logits, None, cand[0])
-        tree_mask[:, 1:acc_n[1]] += diag_one[:, 1:acc_n[1]]
-        current_tree_mask = tree_mask[:, 1:acc_n[1], :acc_n[1]]
-        all_spec[:, 1:acc_n[1]] = pred_ids
-        history_logp_sum[:, 1:acc_n[1]] = topk_logp
+        topk_logp, pred_ids = ops.logprob_topk(logits, None, cand[0])
+        # the root's children (:1021-1027): tree_mask rows + diagonal, all_spec, log-prob sums, and
+        # `draft_cache_lens += a - 1` -- one launch, which also hands back the next pass's positions and packed mask
+        position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp, pred_ids, vocab_size, 0, 1,
+                                                base=st.draft_cache_lens, base_add=a - 1)
         # ---- D1..: tree levels (:1029-1075)
         for ms in range(1, gamma):
-            pred_num = cand[ms]
-            hidden_states = self.model.embed_tokens(all_spec[:, acc_n[ms - 1]:acc_n[ms]])
-            ctm = current_tree_mask.contiguous()
-            position_ids = self.ops.tree_positions(ctm, st.draft_cache_lens)                              # p + depth (:1032)
-            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            lo, mid = acc_n[ms - 1], acc_n[ms]
+            hidden_states = self.model.embed_tokens(all_spec[:, lo:mid])
+            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)                    # p + depth (:1032)
             hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                        llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
                                        llm_kv_len=st.target_cache_lens_for_draft, exec_type="tree_decoding",
-                                       tree_mask=ctm)
+                                       tree_mask=tree_mask[:, lo:mid, :mid], tree_mask_bits=mask_bits)
             # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
-            topk_logp_sum, topk_indices = self.ops.logprob_topk(self.lm_head(hidden_states),
-                                                                history_logp_sum[:, acc_n[ms - 1]:acc_n[ms]], pred_num)
-            father_ids = topk_indices // vocab_size + acc_n[ms - 1]
-            pred_ids = topk_indices % vocab_size
-            tree_mask[:, acc_n[ms]:acc_n[ms + 1]] = (torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn))
-                                                     + diag_one[:, acc_n[ms]:acc_n[ms + 1]])
-            current_tree_mask = tree_mask[:, acc_n[ms]:acc_n[ms + 1], :acc_n[ms + 1]]
-            all_spec[:, acc_n[ms]:acc_n[ms + 1]] = pred_ids
-            history_logp_sum[:, acc_n[ms]:acc_n[ms + 1]] = topk_logp_sum
-        st.draft_cache_lens += 1
-        # ---- V: one R-row target pass (:1078-1091)
-        veri_spec = tree_mask.new_zeros((bsz, R))
-        veri_spec[:, :a] = st.acc_ids
-        veri_spec[:, a:a + Fn - 1] = all_spec[:, 1:]
-        new_tree_mask = st.tril.clone()[None].expand(bsz, -1, -1).contiguous()
-        new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
-        new_tree_mask = torch.tril(new_tree_mask)
-        hidden_states = self.model.forward(veri_spec, cache_lens=st.cache_lens, exec_type="tree_decoding",
-                                           tree_mask=new_tree_mask).last_hidden_state
+            topk_logp_sum, topk_indices = ops.logprob_topk(self.lm_head(hidden_states), history_logp_sum[:, lo:mid], cand[ms])
+            # father = index // vocab, token = index % vocab, mask row = father's row + diagonal (:1056-1075)
+            position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp_sum, topk_indices,
+                                                    vocab_size, lo, mid, base=st.draft_cache_lens, want_next=ms + 1 < gamma)
+        # ---- V: one R-row target pass (:1078-1091); `draft_cache_lens += 1` (:1076) rides in the input assembly
+        veri_spec, position_ids, mask_bits = ops.tree_verify_inputs(st.acc_ids, a, all_spec, tree_mask, st.cache_lens, R,
+                                                                    bump=st.draft_cache_lens, bump_add=1)
+        hidden_states = self.model.forward(veri_spec, position_ids=position_ids, cache_lens=st.cache_lens,
+                                           exec_type="tree_decoding", tree_mask_bits=mask_bits).last_hidden_state
         hidden_states = hidden_states[:, a - 1:a + Fn - 1]
-        all_llm_pred = self.ops.argmax_rows(self.lm_head(hidden_states))
-        # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116)
-        st.cache_lens += a - 1
+        all_llm_pred = ops.argmax_rows(self.lm_head(hidden_states))
+        # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116); the accepted rows start at
+        # cache_lens + a - 1 (:1104), the cache lengths themselves advance in the commit below
         sh = last_attn.shard
         if sh is None:
-            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
-                all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, last_attn.K_Cache, last_attn.V_Cache)
+            kv_lens, kc, vc = st.cache_lens, last_attn.K_Cache, last_attn.V_Cache
         elif sh.is_tail:      # the accepted rows live in the tail owner's local cache
-            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
-                all_spec, all_llm_pred, tree_mask, sh.local_len(st.cache_lens), acc_n[-2], gamma + 1,
-                last_attn.K_Cache, last_attn.V_Cache)
+            kv_lens, kc, vc = sh.local_len(st.cache_lens), last_attn.K_Cache, last_attn.V_Cache
         else:
-            acc_pad, acc_num_t, double_input, _ = self.ops.tree_collapse(
-                all_spec, all_llm_pred, tree_mask, st.cache_lens, acc_n[-2], gamma + 1, None, None)
-        st.cache_lens += 1
-        # emitted tokens -> output_ids (device-side, fixed shape), EOS test on the whole buffer as the
-        # reference does (:1120, G8), then ONE host read for (acc_num, eos flag)
-        emitted = st.emitted
-        sl = st.output_ids[:, emitted:emitted + gamma + 1]
-        keep = st.arange_g < acc_num_t[:, None]
-        sl.copy_(torch.where(keep, acc_pad, sl))
-        hit_t = st.output_ids.eq(st.eos).any().to(torch.int64) if st.eos is not None else acc_num_t.new_zeros(())
-        a, hit = [int(v) for v in torch.stack([acc_num_t[0], hit_t]).tolist()]
+            kv_lens, kc, vc = st.cache_lens, None, None
+        acc_pad, acc_num_t, double_input, _ = ops.tree_collapse(all_spec, all_llm_pred, tree_mask, kv_lens, acc_n[-2],
+                                                                gamma + 1, kc, vc, cache_len_add=a - 1)
+        # emitted tokens -> output_ids, the EOS test on the whole buffer as the reference does (:1120, G8), the tree
+        # state reset and `cache_lens += a`, `target_cache_lens_for_draft += acc_num` (:1104-1117): one launch, then
+        # ONE host read for (acc_num, eos flag)
+        state = ops.tree_commit(acc_pad, acc_num_t, st.output_ids, st.emitted, st.eos, tree_mask, all_spec, history_logp_sum,
+                                target_lens=st.cache_lens, target_add=a, draft_kv_lens=st.target_cache_lens_for_draft)
+        state = state.tolist()
+        a, hit = state[0][0], any(row[1] for row in state)
         st.acc_ids = acc_pad[:, :a]
         st.a = a
-        st.target_cache_lens_for_draft += a
         st.emitted += a
         st.count += a - 1
         st.num += bsz
-        tree_mask.fill_(0)
-        tree_mask[:, :, 0] = 1
-        all_spec.fill_(0)
-        all_spec[:, 0] = st.acc_ids[:, a - 1]
         if st.emitted + gamma + 2 > st.output_ids.size(1):            # :1118
             return False
         if hit:                                                       # :1120

@@ -613,11 +613,77 @@ def tree_positions(tree_mask: torch.Tensor, base: Optional[torch.Tensor]) -> tor
     return pos
 
 
+def _tree_state(tree_mask, all_spec, logp_sum=None):
+    """The in-place tree operators work on the round's state tensors as they are."""
+    b, Fn = all_spec.shape
+    if tree_mask.dtype != torch.int64 or all_spec.dtype != torch.int64 or tuple(tree_mask.shape) != (b, Fn, Fn):
+        raise TypeError("tree state: tree_mask [b,F,F] and all_spec [b,F] must be int64")
+    if not (tree_mask.is_contiguous() and all_spec.is_contiguous()):
+        raise ValueError("tree state tensors must be contiguous")
+    if logp_sum is not None and (logp_sum.dtype != torch.float32 or tuple(logp_sum.shape) != (b, Fn) or not logp_sum.is_contiguous()):
+        raise TypeError("tree state: logp_sum must be contiguous fp32 [b,F]")
+    return b, Fn
+
+
+def _len_i32(t, b, name):
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or t.numel() != b or not t.is_contiguous():
+        raise TypeError(f"{name} must be a contiguous int32 [b] tensor (it is updated in place)")
+    return t.data_ptr()
+
+
+def tree_grow(tree_mask, all_spec, logp_sum, topk_vals, topk_idx, vocab: int, lo: int, mid: int,
+              base: Optional[torch.Tensor] = None, base_add: int = 0, want_next: bool = True):
+    """One more tree level, in place on the round's state (``llama_glide.py:1021-1027``, ``:1056-1075``):
+    node mid+j = child of node ``lo + topk_idx[j] // vocab`` with token ``topk_idx[j] % vocab`` and cumulative
+    log-prob ``topk_vals[j]``; its mask row = the father's row + the diagonal.  Returns (position_ids [b,k],
+    packed mask bits [b,k,words]) of the new level for the draft pass that runs next (None, None when
+    ``want_next`` is False); ``base`` [b] int32 is the draft cache length and is advanced by ``base_add`` first."""
+    _dev(tree_mask, all_spec, logp_sum, topk_vals, topk_idx, base)
+    b, Fn = _tree_state(tree_mask, all_spec, logp_sum)
+    k = topk_idx.shape[-1]
+    vals = topk_vals.to(torch.float32).contiguous().view(b, k)
+    idx = topk_idx.to(torch.int64).contiguous().view(b, k)
+    pos = bits = None
+    words = (mid + k + 31) // 32
+    if want_next:
+        pos = torch.empty((b, k), dtype=torch.int64, device=idx.device)
+        bits = torch.empty((b, k, words), dtype=torch.int32, device=idx.device)
+    lib = _C.load()
+    _C.check(lib.ls_tree_grow(tree_mask.data_ptr(), all_spec.data_ptr(), logp_sum.data_ptr(), vals.data_ptr(), idx.data_ptr(),
+                              b, Fn, k, int(vocab), lo, mid, _len_i32(base, b, "base"), base_add,
+                              pos.data_ptr() if want_next else None, bits.data_ptr() if want_next else None, words, _stream()),
+             "ls_tree_grow")
+    return pos, bits
+
+
+def tree_verify_inputs(acc_ids, a: int, all_spec, tree_mask, cache_lens, R: int, bump: Optional[torch.Tensor] = None,
+                       bump_add: int = 0):
+    """Token ids, position ids and packed tree mask of the R-row verification pass (``llama_glide.py:1078-1086``):
+    rows = [a accepted tokens | the F-1 tree nodes | pads].  ``bump`` [b] int32 += ``bump_add`` (:1076)."""
+    _dev(acc_ids, all_spec, tree_mask, cache_lens, bump)
+    b, Fn = _tree_state(tree_mask, all_spec)
+    if acc_ids.dtype != torch.int64 or acc_ids.dim() != 2 or acc_ids.shape[1] < a or acc_ids.stride(1) != 1:
+        raise TypeError("acc_ids must be int64 [b, >=a] with a contiguous last dimension")
+    dev = all_spec.device
+    words = (R + 31) // 32
+    veri = torch.empty((b, R), dtype=torch.int64, device=dev)
+    pos = torch.empty((b, R), dtype=torch.int64, device=dev)
+    bits = torch.empty((b, R, words), dtype=torch.int32, device=dev)
+    lib = _C.load()
+    _C.check(lib.ls_tree_verify_inputs(acc_ids.data_ptr(), acc_ids.stride(0), a, all_spec.data_ptr(), tree_mask.data_ptr(), b, Fn,
+                                       R, _len_i32(cache_lens, b, "cache_lens"), veri.data_ptr(), pos.data_ptr(),
+                                       bits.data_ptr(), words, _len_i32(bump, b, "bump"), bump_add, _stream()),
+             "ls_tree_verify_inputs")
+    return veri, pos, bits
+
+
 def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: int, max_acc: int,
-                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None):
+                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None, cache_len_add: int = 0):
     """Accept/reject tree collapse + last-layer KV row move, one launch, no host sync.
     Returns (acc_ids [b,max_acc] int64 zero-padded, acc_num [b] int64, double_input [b] int32,
-    index_mapping [b,max_acc] int64, -1 padded)."""
+    index_mapping [b,max_acc] int64, -1 padded).  The moved rows start at ``cache_lens + cache_len_add``."""
     _dev(all_spec, all_llm_pred, tree_mask, cache_lens, k_cache, v_cache)
     b, Fn = all_spec.shape
     dev = all_spec.device
@@ -634,12 +700,53 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: i
         if k_cache.stride() != v_cache.stride() or k_cache.stride(3) != 1 or k_cache.stride(2) != k_cache.shape[3]:
             raise ValueError("tree_collapse: cache rows must be contiguous [Hkv*D]")
         row_elems = k_cache.shape[2] * k_cache.shape[3]
-        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), b, Fn, non_leaf_len,
-                                      max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(), imap.data_ptr(),
-                                      k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
-                                      row_elems, _dtype(k_cache), _stream()), "ls_tree_collapse")
+        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), cache_len_add, b, Fn,
+                                      non_leaf_len, max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(),
+                                      imap.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(0),
+                                      k_cache.stride(1), row_elems, _dtype(k_cache), _stream()), "ls_tree_collapse")
     else:
-        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), b, Fn, non_leaf_len,
-                                      max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(), imap.data_ptr(),
-                                      None, None, 0, 0, 0, 0, _stream()), "ls_tree_collapse")
+        _C.check(lib.ls_tree_collapse(spec.data_ptr(), pred.data_ptr(), tm.data_ptr(), cl.data_ptr(), cache_len_add, b, Fn,
+                                      non_leaf_len, max_acc, acc_ids.data_ptr(), acc_num.data_ptr(), dbl.data_ptr(),
+                                      imap.data_ptr(), None, None, 0, 0, 0, 0, _stream()), "ls_tree_collapse")
     return acc_ids, acc_num, dbl, imap
+
+
+def tree_commit(acc_ids, acc_num, output_ids, emitted: int, eos: Optional[int], tree_mask, all_spec, logp_sum,
+                target_lens: Optional[torch.Tensor] = None, target_add: int = 0,
+                draft_kv_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """End of a round (``llama_glide.py:1093-1121``) in one launch: the accepted ids go to
+    ``output_ids[:, emitted:]``, the tree state is reset for the next round (mask = root column, all_spec[0] =
+    the last accepted id, log-prob sums = 0), ``target_lens += target_add``, ``draft_kv_lens += acc_num``.
+    Returns state [b,2] int64 = (acc_num, whole-buffer EOS hit) -- the round's one host read."""
+    _dev(acc_ids, acc_num, output_ids, tree_mask, all_spec, logp_sum, target_lens, draft_kv_lens)
+    b, Fn = _tree_state(tree_mask, all_spec, logp_sum)
+    if output_ids.dtype != torch.int64 or output_ids.stride(1) != 1 or not acc_ids.is_contiguous() or acc_ids.dtype != torch.int64:
+        raise TypeError("tree_commit: output_ids / acc_ids must be int64 with contiguous rows")
+    state = torch.empty((b, 2), dtype=torch.int64, device=all_spec.device)
+    lib = _C.load()
+    _C.check(lib.ls_tree_commit(acc_ids.data_ptr(), acc_num.data_ptr(), b, acc_ids.shape[1], output_ids.data_ptr(),
+                                output_ids.stride(0), output_ids.shape[1], emitted, 0 if eos is None else 1,
+                                0 if eos is None else int(eos), state.data_ptr(), tree_mask.data_ptr(), all_spec.data_ptr(),
+                                logp_sum.data_ptr(), Fn, _len_i32(target_lens, b, "target_lens"), target_add,
+                                _len_i32(draft_kv_lens, b, "draft_kv_lens"), _stream()), "ls_tree_commit")
+    return state
+
+
+EMBED_MAX_ROWS = 128
+
+
+def embed_supported(ids: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Short passes gather their embedding rows with ``ls_embed_rows``; prefill-sized inputs use the library."""
+    return (ids.is_cuda and weight.is_cuda and 0 < ids.numel() <= EMBED_MAX_ROWS and weight.dtype in (torch.float16, torch.bfloat16)
+            and weight.is_contiguous() and weight.shape[1] % 8 == 0)
+
+
+def embed_rows(weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """``embed_tokens(ids)`` (``llama.py:579``): out[..., :] = weight[ids]."""
+    _dev(weight, ids)
+    flat = ids.to(torch.int64).contiguous().view(-1)
+    out = torch.empty((flat.numel(), weight.shape[1]), dtype=weight.dtype, device=weight.device)
+    lib = _C.load()
+    _C.check(lib.ls_embed_rows(weight.data_ptr(), weight.shape[0], weight.shape[1], _dtype(weight), flat.data_ptr(), flat.numel(),
+                               out.data_ptr(), _stream()), "ls_embed_rows")
+    return out.view(*ids.shape, weight.shape[1])

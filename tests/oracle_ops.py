@@ -49,10 +49,72 @@ def draft_tree_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bit
     return ref_ops.draft_tree_self_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, window)
 
 
-def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache=None, v_cache=None):
+def tree_grow(tree_mask, all_spec, logp_sum, topk_vals, topk_idx, vocab, lo, mid, base=None, base_add=0, want_next=True):
+    """The reference's tensor ops for one more tree level (llama_glide.py:1021-1027 / :1056-1075), in place."""
+    Fn = tree_mask.shape[1]
+    k = topk_idx.shape[-1]
+    hi = mid + k
+    diag_one = torch.eye(Fn, dtype=torch.int64)[None].expand(tree_mask.shape[0], -1, -1)
+    if lo == 0 and mid == 1:                                       # root's children (:1021-1024)
+        tree_mask[:, 1:hi] += diag_one[:, 1:hi]
+        all_spec[:, 1:hi] = topk_idx
+    else:                                                          # :1056-1069
+        father_ids = topk_idx // vocab + lo
+        tree_mask[:, mid:hi] = torch.gather(tree_mask, 1, father_ids[:, :, None].expand(-1, -1, Fn)) + diag_one[:, mid:hi]
+        all_spec[:, mid:hi] = topk_idx % vocab
+    logp_sum[:, mid:hi] = topk_vals
+    if base is not None and base_add:
+        base += base_add
+    if not want_next:
+        return None, None
+    ctm = tree_mask[:, mid:hi, :hi].contiguous()
+    return tree_positions(ctm, base), pack_tree_mask(ctm)
+
+
+def tree_verify_inputs(acc_ids, a, all_spec, tree_mask, cache_lens, R, bump=None, bump_add=0):
+    """llama_glide.py:1078-1086 with the reference's tensor ops."""
+    bsz, Fn = all_spec.shape
+    veri_spec = tree_mask.new_zeros((bsz, R))
+    veri_spec[:, :a] = acc_ids[:, :a]
+    veri_spec[:, a:a + Fn - 1] = all_spec[:, 1:]
+    new_tree_mask = torch.tril(torch.ones((R, R), dtype=torch.int64))[None].expand(bsz, -1, -1).contiguous()
+    new_tree_mask[:, a:a + Fn - 1, a:a + Fn - 1] = tree_mask[:, 1:, 1:]
+    new_tree_mask = torch.tril(new_tree_mask)
+    if bump is not None and bump_add:
+        bump += bump_add
+    return veri_spec, tree_positions(new_tree_mask, cache_lens), pack_tree_mask(new_tree_mask)
+
+
+def tree_commit(acc_ids, acc_num, output_ids, emitted, eos, tree_mask, all_spec, logp_sum, target_lens=None, target_add=0,
+                draft_kv_lens=None):
+    """llama_glide.py:1093-1121 with the reference's tensor ops."""
+    g = acc_ids.shape[1]
+    sl = output_ids[:, emitted:emitted + g]
+    keep = torch.arange(g)[None, :sl.shape[1]] < acc_num[:, None]
+    sl.copy_(torch.where(keep, acc_ids[:, :sl.shape[1]], sl))
+    hit = output_ids.eq(eos).any(dim=-1).to(torch.int64) if eos is not None else torch.zeros_like(acc_num)
+    last = torch.gather(acc_ids, 1, (acc_num[:, None] - 1).clamp(min=0))[:, 0]
+    tree_mask.fill_(0)
+    tree_mask[:, :, 0] = 1
+    all_spec.fill_(0)
+    all_spec[:, 0] = last
+    logp_sum.zero_()
+    if target_lens is not None:
+        target_lens += target_add
+    if draft_kv_lens is not None:
+        draft_kv_lens += acc_num.to(draft_kv_lens.dtype)
+    return torch.stack([acc_num, hit], dim=1)
+
+
+def embed_supported(ids, weight):
+    return False
+
+
+def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache=None, v_cache=None,
+                  cache_len_add=0):
     acc_ids, acc_num, dbl, imap = ref_ops.tree_verification(all_spec, all_llm_pred, tree_mask, non_leaf_len)
     if k_cache is not None:
-        ref_ops.move_accepted_kv(k_cache, v_cache, cache_lens, imap)
+        ref_ops.move_accepted_kv(k_cache, v_cache, cache_lens + cache_len_add, imap)
     b, n = acc_ids.shape
     pad_ids = torch.zeros((b, max_acc), dtype=torch.int64)
     pad_map = torch.full((b, max_acc), -1, dtype=torch.int64)
