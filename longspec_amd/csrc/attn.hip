@@ -1174,53 +1174,90 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     const long part_o_stride = p.part_o_stride;
     const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
 
-    // pass 1: reference max over the parts (independent scalar loads)
-    float mx = -INFINITY;
-#pragma unroll 8
-    for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, p.parts_lse[i * part_lse_stride + lse_idx]);
     float lnew = -INFINITY;
     if (p.new_o != nullptr) lnew = p.new_lse[lse_idx];
-    if (joint) mx = fmaxf(mx, lnew);
-    const float mref = mx == -INFINITY ? 0.f : mx;
-    // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
-    // o = 0) so that 8 independent 16-byte loads are in flight per thread
-    float den = 0.f;
+    float mref, den = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    int i = 0;
-    for (; i + 8 <= p.n_parts; i += 8) {
-        float l8[8];
-        f32x4 o8[8];
+    const int n = p.n_parts;
+    if (n >= 1 && n <= 32) {
+        // every load of the merge is issued before the first use: the kernel is one wave per SIMD and pure latency,
+        // so the number of dependent load batches is its run time.  Parts beyond n re-read part n-1 with weight 0.
+        float l[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            l8[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
-            o8[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+        for (int u = 0; u < 32; ++u) l[u] = p.parts_lse[(u < n ? u : n - 1) * part_lse_stride + lse_idx];
+        f32x4 oa[16], ob[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            oa[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (u < n ? u : n - 1) * part_o_stride + o_idx);
+        if (n > 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                ob[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (16 + u < n ? 16 + u : n - 1) * part_o_stride + o_idx);
         }
+        float mx = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float wgt = expf(l8[u] - mref);
+        for (int u = 0; u < 32; ++u) mx = fmaxf(mx, u < n ? l[u] : -INFINITY);
+        if (joint) mx = fmaxf(mx, lnew);
+        mref = mx == -INFINITY ? 0.f : mx;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float wgt = u < n ? expf(l[u] - mref) : 0.f;
             den += wgt;
-            o += o8[u] * wgt;
+            o += oa[u] * wgt;
         }
-    }
-    for (; i + 4 <= p.n_parts; i += 4) {
-        float l4[4];
-        f32x4 o4[4];
+        if (n > 16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            l4[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
-            o4[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+            for (int u = 0; u < 16; ++u) {
+                const float wgt = 16 + u < n ? expf(l[16 + u] - mref) : 0.f;
+                den += wgt;
+                o += ob[u] * wgt;
+            }
         }
+    } else {
+        // pass 1: reference max over the parts (independent scalar loads)
+        float mx = -INFINITY;
+#pragma unroll 8
+        for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, p.parts_lse[i * part_lse_stride + lse_idx]);
+        if (joint) mx = fmaxf(mx, lnew);
+        mref = mx == -INFINITY ? 0.f : mx;
+        // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
+        // o = 0) so that 8 independent 16-byte loads are in flight per thread
+        int i = 0;
+        for (; i + 8 <= p.n_parts; i += 8) {
+            float l8[8];
+            f32x4 o8[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float wgt = expf(l4[u] - mref);
+            for (int u = 0; u < 8; ++u) {
+                l8[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
+                o8[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float wgt = expf(l8[u] - mref);
+                den += wgt;
+                o += o8[u] * wgt;
+            }
+        }
+        for (; i + 4 <= p.n_parts; i += 4) {
+            float l4[4];
+            f32x4 o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                l4[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
+                o4[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wgt = expf(l4[u] - mref);
+                den += wgt;
+                o += o4[u] * wgt;
+            }
+        }
+        for (; i < p.n_parts; ++i) {
+            const float wgt = expf(p.parts_lse[i * part_lse_stride + lse_idx] - mref);
             den += wgt;
-            o += o4[u] * wgt;
+            o += *reinterpret_cast<const f32x4*>(p.parts_o + i * part_o_stride + o_idx) * wgt;
         }
-    }
-    for (; i < p.n_parts; ++i) {
-        const float wgt = expf(p.parts_lse[i * part_lse_stride + lse_idx] - mref);
-        den += wgt;
-        o += *reinterpret_cast<const f32x4*>(p.parts_o + i * part_o_stride + o_idx) * wgt;
     }
     if (joint && lnew != -INFINITY) {
         const float wgt = expf(lnew - mref);

@@ -64,6 +64,66 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const typename E::T* __res
     }
 }
 
+// Short-chain variant for the decode passes (<= 80 rows, a launch is pure latency): one 8-element chunk per thread
+// (NCH of them for hidden > 8192), every global load -- x, residual AND weight -- issued before the first use,
+// the row kept in registers, one barrier.
+template <typename E, int NCH>
+__global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T* __restrict__ x,
+                                                            const typename E::T* __restrict__ res,
+                                                            const typename E::T* __restrict__ wgt, typename E::T* __restrict__ y,
+                                                            typename E::T* __restrict__ sum_out, int hidden, float eps) {
+    __shared__ float red[16];
+    const long base = (long)blockIdx.x * hidden;
+    const int tid = threadIdx.x, T = blockDim.x;
+    typename E::V8 v[NCH], r[NCH], w8[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * T + tid) * 8;
+        if (i < hidden) {
+            v[c] = *reinterpret_cast<const typename E::V8*>(x + base + i);
+            if (res) r[c] = *reinterpret_cast<const typename E::V8*>(res + base + i);
+            w8[c] = *reinterpret_cast<const typename E::V8*>(wgt + i);
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * T + tid) * 8;
+        if (i < hidden) {
+            if (res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = E::from_f32(E::to_f32(r[c][e]) + E::to_f32(v[c][e]));
+                if (sum_out) *reinterpret_cast<typename E::V8*>(sum_out + base + i) = v[c];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = E::to_f32(v[c][e]);
+                ss += f * f;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int wv = 0; wv < (T >> 6); ++wv) tot += red[wv];
+    const float rs = rsqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i = (c * T + tid) * 8;
+        if (i < hidden) {
+            typename E::V8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = round_to<E>(E::to_f32(v[c][e]) * rs);
+                o[e] = E::from_f32(E::to_f32(w8[c][e]) * n);
+            }
+            *reinterpret_cast<typename E::V8*>(y + base + i) = o;
+        }
+    }
+}
+
 // ---- RoPE -------------------------------------------------------------------------------
 // cos/sin[r][d] = dtype( {cos,sin}( float(pos[r]) * inv_freq[d % 64] ) * scaling )
 // (fp32 product like the reference's K=1 matmul; the transcendental is evaluated in
@@ -137,17 +197,41 @@ const char* ls_last_error(void) { return g_err; }
 int ls_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void* y, void* sum_out, int rows, int hidden,
                    float eps, int dtype, void* stream) {
     if (!x || !weight || !y || rows < 1 || hidden < 8 || (hidden & 7)) LS_FAIL(LS_ERR_INVALID_ARG, "rmsnorm args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
+    const int chunks = hidden / 8;
+    if (rows <= 128 && chunks <= 4096) {
+        // decode-shaped call: chunk-per-thread kernel
+        int T = ((chunks + 63) / 64) * 64;
+        int nch = 1;
+        if (T > 1024) {
+            nch = chunks <= 2048 ? 2 : 4;
+            T = (((chunks + nch - 1) / nch + 63) / 64) * 64;
+        }
+#define LS_NORM_ROWS(EL, TY, N)                                                                                           \
+    hipLaunchKernelGGL((rmsnorm_rows_kernel<EL, N>), dim3(rows), dim3(T), 0, s, (const TY*)x, (const TY*)residual,        \
+                       (const TY*)weight, (TY*)y, (TY*)sum_out, hidden, eps)
+        if (dtype == LS_F16) {
+            if (nch == 1) LS_NORM_ROWS(ElemF16, _Float16, 1);
+            else if (nch == 2) LS_NORM_ROWS(ElemF16, _Float16, 2);
+            else LS_NORM_ROWS(ElemF16, _Float16, 4);
+        } else {
+            if (nch == 1) LS_NORM_ROWS(ElemBF16, __bf16, 1);
+            else if (nch == 2) LS_NORM_ROWS(ElemBF16, __bf16, 2);
+            else LS_NORM_ROWS(ElemBF16, __bf16, 4);
+        }
+#undef LS_NORM_ROWS
+        LS_CHECK_LAUNCH("rmsnorm_rows_kernel");
+        return LS_OK;
+    }
     const size_t lds = ((hidden * 2 + 15) & ~15) + 16;
     if (lds > 64 * 1024) LS_FAIL(LS_ERR_UNSUPPORTED, "hidden %d too large", hidden);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == LS_F16)
         hipLaunchKernelGGL(rmsnorm_kernel<ElemF16>, dim3(rows), dim3(256), lds, s, (const _Float16*)x,
                            (const _Float16*)residual, (const _Float16*)weight, (_Float16*)y, (_Float16*)sum_out, hidden, eps);
-    else if (dtype == LS_BF16)
+    else
         hipLaunchKernelGGL(rmsnorm_kernel<ElemBF16>, dim3(rows), dim3(256), lds, s, (const __bf16*)x,
                            (const __bf16*)residual, (const __bf16*)weight, (__bf16*)y, (__bf16*)sum_out, hidden, eps);
-    else
-        LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
     LS_CHECK_LAUNCH("rmsnorm_kernel");
     return LS_OK;
 }

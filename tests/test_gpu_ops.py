@@ -59,6 +59,28 @@ def test_rmsnorm_residual(ops):
     assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=8e-3, frac=0.002, mean=1e-5, what="rmsnorm+res")
 
 
+@pytest.mark.parametrize("rows,hidden", [(1, 4096), (74, 5120), (16, 8192), (5, 16384), (3, 24576), (7, 40), (80, 1000),
+                                         (200, 4096), (130, 512)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_rmsnorm_shapes(ops, rows, hidden, dtype):
+    """Decode-shaped calls (<= 128 rows: chunk-per-thread kernel, 1/2/4 chunks) and prefill-shaped ones, both dtypes."""
+    x = toy.randn_f16((rows, hidden), rows).to(dtype)
+    r = toy.randn_f16((rows, hidden), hidden).to(dtype)
+    w = (toy.randn_f16((hidden,), 3) * 0.1 + 1).to(dtype)
+    y, s = ops.rmsnorm(g(x), g(w), 1e-6, residual=g(r))
+    s_ref = r + x
+    assert torch.equal(s.cpu(), s_ref)
+    want = ref_ops.rmsnorm(s_ref, w, 1e-6)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    d = (y.float().cpu() - want.float()).abs()
+    # the normalised value is rounded before the weight product (llama.py LlamaRMSNorm): a 1-ulp flip there can
+    # land 2 ulps apart after the second rounding
+    assert (d <= 2 * ulp * want.float().abs().clamp(min=1e-2)).all()
+    assert (d > 0).float().mean().item() < 0.01
+    y2 = ops.rmsnorm(g(s_ref), g(w), 1e-6)
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("c", list(cases.rope_cases()), ids=lambda c: c["name"])
 def test_rope_golden(ops, c):
     cos, sin = ops.rope_cos_sin(g(c["pos"]), g(c["inv_freq"]), c["scaling"], torch.float16)
