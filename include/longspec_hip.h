@@ -128,6 +128,8 @@ int ls_pack_tree_mask(const int64_t* tree_mask, int b, int M, int N, uint32_t* b
 
 #define LS_EPI_NONE 0     /* y = x W^T (+ bias)                                                     */
 #define LS_EPI_SILU_MUL 1 /* y = silu(x Wg^T) * (x Wu^T): w[0] = ls_linear_pack_gate_up(Wg, Wu), n[0] = N */
+#define LS_EPI_QKV_ROPE 2 /* q|k|v projection + apply_rotary_pos_emb on q and k (llama.py:375-378): segments 0 and 1
+                           * are packed by ls_linear_pack_rope and rotated with rope_cos/rope_sin, segment 2 is plain */
 
 typedef struct ls_linear_desc {
     const void* x;        /* [M, K] dtype, row stride ldx (elements)                                  */
@@ -143,6 +145,8 @@ typedef struct ls_linear_desc {
     int32_t epilogue;     /* LS_EPI_*                                                                 */
     int32_t n_splits;     /* split-K factor, 0 = automatic (a function of N, K only -- never of M)    */
     int64_t ldx, ldy;
+    const void* rope_cos; /* LS_EPI_QKV_ROPE: cos / sin [M, 128] dtype of the rows' positions (ls_rope_cos_sin) */
+    const void* rope_sin;
 } ls_linear_desc;
 
 /* Weights are streamed in the MFMA A-operand layout: pack each nn.Linear.weight [N, K] (row-major,
@@ -157,6 +161,11 @@ int ls_linear_pack_weight(const void* weight, void* packed, int N, int K, int dt
  * whose 16-row tiles alternate gate, up, gate, up ...: the operand of LS_EPI_SILU_MUL.  N % 16 == 0. */
 int ls_linear_pack_gate_up(const void* gate_weight, const void* up_weight, void* packed, int N, int K,
                            int dtype, void* stream);
+
+/* A q_proj / k_proj weight [heads*128, K] for LS_EPI_QKV_ROPE: same block structure, but within every head the
+ * 16-row tiles are stored in the order 0,4,1,5,2,6,3,7 so that rows d and d+64 -- a rotary pair -- are finished by
+ * the same wave.  The output columns are the plain ones. */
+int ls_linear_pack_rope(const void* weight, void* packed, int N, int K, int dtype, void* stream);
 
 /* Bytes of workspace (slab counters + split-K partials).  The workspace must be ZERO-FILLED once
  * before its first use; every call leaves the counter region zero again, so one workspace can serve

@@ -34,7 +34,7 @@ class AttnDesc(C.Structure):
     ]
 
 
-LS_EPI_NONE, LS_EPI_SILU_MUL = 0, 1
+LS_EPI_NONE, LS_EPI_SILU_MUL, LS_EPI_QKV_ROPE = 0, 1, 2
 
 
 class LinearDesc(C.Structure):
@@ -45,6 +45,7 @@ class LinearDesc(C.Structure):
         ("M", C.c_int32), ("K", C.c_int32), ("n", C.c_int32 * 3), ("n_seg", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("n_splits", C.c_int32),
         ("ldx", C.c_int64), ("ldy", C.c_int64),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
     ]
 
 
@@ -64,6 +65,7 @@ SYMBOLS = {
     "ls_linear_packed_bytes": (C.c_size_t, [_I, _I]),
     "ls_linear_pack_weight": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "ls_linear_pack_gate_up": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "ls_linear_pack_rope": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "ls_linear_workspace_bytes": (C.c_size_t, [C.POINTER(LinearDesc)]),
     "ls_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), _P, C.c_size_t, _P]),
     "ls_topk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),

@@ -56,9 +56,12 @@ struct GemmK {
     int M, K, N;                 // N = total output columns
     int nks, S, nslabs;          // nks = K / 32 k-steps
     int flag_off;                // byte offset of the last-arriver flag in dynamic LDS
+    const char* rope_cos;        // EPI_QKV_ROPE: [M, 128] dtype tables of the rows' positions
+    const char* rope_sin;
+    int rope_segs;               // leading segments (q, k) that are rotated; the rest (v) are plain
 };
 
-enum { EPI_NONE = 0, EPI_SILU_MUL = 1 };
+enum { EPI_NONE = 0, EPI_SILU_MUL = 1, EPI_QKV_ROPE = 2 };
 
 // agent-coherent accesses (sc1: write-through / cache-bypassing), so that partials written by a workgroup
 // on one XCD are read correctly by the reducing workgroup on another without an L2 write-back + invalidate
@@ -95,15 +98,17 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     // ---- the NT weight tiles of this workgroup.  Packed block (64-row group g, k-step s, tile t) is the 1 KB
     // at ((g * nks + s) * 4 + t) * 1024.  EPI_SILU_MUL: the packed matrix alternates gate and up tiles (tile 2j =
     // gate rows 16j.., tile 2j+1 = up rows 16j..), so tiles (2j, 2j+1) make output columns 16j..16j+15.
+    // EPI_QKV_ROPE: like EPI_NONE, but the q and k segments are packed by ls_linear_pack_rope (within each 128-row
+    // head, tile 2j = rows 16j.., tile 2j+1 = rows 64+16j..: a rotary pair sits in neighbouring tiles).
     const char* wtile[NT];
     const char* bias_p = nullptr;
     int n_lim;                   // end of the valid output columns of this slab's segment (global column)
     int n_tile0;                 // global output column of tile 0
+    int seg_base = 0, seg = 0;
     const long group_b = (long)p.nks * 4096;
     {
         const int row0 = slab * NT * 16;                 // first packed row of the workgroup (global over segments)
-        int seg_base = 0, seg = 0;
-        if (EPI == EPI_NONE) {
+        if (EPI != EPI_SILU_MUL) {
             if (row0 >= p.n[0]) { seg_base = p.n[0]; seg = 1; }
             if (seg == 1 && row0 >= p.n[0] + p.n[1]) { seg_base = p.n[0] + p.n[1]; seg = 2; }
             bias_p = p.bias[seg] ? p.bias[seg] - (long)seg_base * 2 : nullptr;   // indexable by global column
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
             n_tile0 = row0 >> 1;
             n_lim = p.n[0];
         }
-        const int ngroups = EPI == EPI_NONE ? (p.n[seg] + 63) >> 6 : (2 * p.n[0] + 63) >> 6;
+        const int ngroups = EPI != EPI_SILU_MUL ? (p.n[seg] + 63) >> 6 : (2 * p.n[0] + 63) >> 6;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int g = min(((row0 - seg_base) >> 6) + (t >> 2), ngroups - 1);    // clamp: tiles past the end are never stored
@@ -205,9 +210,11 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     }
 
     // ---- reduce the 4 waves (fixed order) through LDS, 4 tiles per pass.  EPI_NONE: wave w finishes tile
-    // 4h + w of pass h.  EPI_SILU_MUL: waves 0,1 finish the (gate, up) pair 4h + 2w, 4h + 2w + 1.
-    constexpr int NT_OUT = EPI == EPI_SILU_MUL ? 2 : 1;      // tiles per finishing wave per pass
-    const bool finisher = EPI == EPI_SILU_MUL ? wave < 2 : true;
+    // 4h + w of pass h.  EPI_SILU_MUL / EPI_QKV_ROPE: waves 0,1 finish the tile pair 4h + 2w, 4h + 2w + 1
+    // (gate, up) / (rotary low half, high half).
+    constexpr bool PAIRED = EPI != EPI_NONE;
+    constexpr int NT_OUT = PAIRED ? 2 : 1;                   // tiles per finishing wave per pass
+    const bool finisher = PAIRED ? wave < 2 : true;
     float* red = reinterpret_cast<float*>(smem);
     f32x4 r[NPASS][NT_OUT][MT];
 #pragma unroll
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
         if (finisher) {
 #pragma unroll
             for (int q = 0; q < NT_OUT; ++q) {
-                const int t = EPI == EPI_SILU_MUL ? 2 * wave + q : wave;
+                const int t = PAIRED ? 2 * wave + q : wave;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + t) * MT + mt) * 64 + lane) * 4);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     // ---- split-K: deterministic last-arriver reduction
     if (p.S > 1) {
         constexpr int TILE_F = MT * 4 * 64;                  // floats of one tile's accumulators
-        auto tile_of = [&](int h, int q) { return h * 4 + (EPI == EPI_SILU_MUL ? 2 * wave + q : wave); };
+        auto tile_of = [&](int h, int q) { return h * 4 + (PAIRED ? 2 * wave + q : wave); };
         if (finisher) {
 #pragma unroll
             for (int h = 0; h < NPASS; ++h)
@@ -302,6 +309,52 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
                 }
                 if (m < p.M && nn < n_lim) *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + nn) * 2) = o;
             }
+        } else if (EPI == EPI_QKV_ROPE) {
+            // tiles (2u, 2u+1) of the slab, u = 2h + wave.  Rotated segment: they are rows d.. and 64+d.. of one head;
+            // apply_rotary_pos_emb on the rounded projections exactly as rope_apply_kernel does (misc.hip).
+            const int tl = ((n_tile0 - seg_base) >> 4) + (h * 2 + wave) * 2;          // packed tile index in the segment
+            const bool rot = seg < p.rope_segs;
+            const int d = ((tl & 7) >> 1) * 16 + g4 * 4;                              // dimension of the low half
+            const int n_lo = rot ? seg_base + (tl >> 3) * 128 + d : seg_base + tl * 16 + g4 * 4;
+            const int n_hi = rot ? n_lo + 64 : n_lo + 16;
+            float bl[4] = {0.f, 0.f, 0.f, 0.f}, bh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias_p != nullptr) {
+                if (n_lo < n_lim) {
+                    const V4 b4 = *reinterpret_cast<const V4*>(bias_p + (long)n_lo * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bl[e] = E::to_f32(b4[e]);
+                }
+                if (n_hi < n_lim) {
+                    const V4 b4 = *reinterpret_cast<const V4*>(bias_p + (long)n_hi * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bh[e] = E::to_f32(b4[e]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 16 + l15;
+                if (m >= p.M) continue;
+                V4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = E::from_f32(r[h][0][mt][e] + bl[e]);
+                    hi[e] = E::from_f32(r[h][1][mt][e] + bh[e]);
+                }
+                if (rot) {
+                    const V4 cl = *reinterpret_cast<const V4*>(p.rope_cos + ((long)m * 128 + d) * 2);
+                    const V4 ch = *reinterpret_cast<const V4*>(p.rope_cos + ((long)m * 128 + 64 + d) * 2);
+                    const V4 sl = *reinterpret_cast<const V4*>(p.rope_sin + ((long)m * 128 + d) * 2);
+                    const V4 sh = *reinterpret_cast<const V4*>(p.rope_sin + ((long)m * 128 + 64 + d) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xl = E::to_f32(lo[e]), xh = E::to_f32(hi[e]);
+                        lo[e] = E::from_f32(round_to<E>(xl * E::to_f32(cl[e])) + round_to<E>(-xh * E::to_f32(sl[e])));
+                        hi[e] = E::from_f32(round_to<E>(xh * E::to_f32(ch[e])) + round_to<E>(xl * E::to_f32(sh[e])));
+                    }
+                }
+                if (n_lo < n_lim) *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + n_lo) * 2) = lo;
+                if (n_hi < n_lim) *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + n_hi) * 2) = hi;
+            }
         } else {
             const int nn = n_tile0 + (h * 4 + wave) * 16 + g4 * 4;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -328,8 +381,10 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
 // (16-bit elements; rows >= N are zero).  A wave multiplying a slab reads 4 KB contiguous per k-step.
 // `w_up` != null packs the gate/up pair of an MLP as ONE matrix of 2N rows whose 16-row tiles alternate: tile 2j =
 // gate rows 16j.., tile 2j+1 = up rows 16j.. (the silu(gate)*up epilogue pairs neighbouring tiles).
+// `rope` packs a q/k projection for EPI_QKV_ROPE: within every 128-row head the 8 tiles are stored in the order
+// 0,4,1,5,2,6,3,7, so that rows d.. and 64+d.. (a rotary pair) are neighbouring tiles of one workgroup.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __restrict__ w, const uint16_t* __restrict__ w_up,
-                                                          uint16_t* __restrict__ out, int N, int K, long nblocks) {
+                                                          uint16_t* __restrict__ out, int N, int K, long nblocks, int rope) {
     const int nks = K >> 5;
     for (long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblocks; blk += (long)gridDim.x * 4) {
         const int t = (int)(blk & 3);
@@ -342,6 +397,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __rest
         if (w_up != nullptr) {
             src = (T & 1) ? w_up : w;
             row = (T >> 1) * 16 + (l & 15);
+        } else if (rope) {
+            row = ((T & ~7) + ((T & 7) >> 1) + 4 * (T & 1)) * 16 + (l & 15);
         }
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < N) v = *reinterpret_cast<const uint4*>(src + (long)row * K + ks * 32 + (l >> 4) * 8);
@@ -407,7 +464,12 @@ int make_plan(const ls_linear_desc* d, Plan& pl) {
         if (d->n[0] < 1 || d->n[0] % 16 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear: silu_mul needs N %% 16 == 0");
         pl.N = d->n[0];
         rows = 2 * d->n[0];
-    } else if (d->epilogue == LS_EPI_NONE) {
+    } else if (d->epilogue == LS_EPI_NONE || d->epilogue == LS_EPI_QKV_ROPE) {
+        if (d->epilogue == LS_EPI_QKV_ROPE) {
+            if (!d->rope_cos || !d->rope_sin) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: qkv_rope needs the cos/sin tables");
+            for (int i = 0; i < d->n_seg; ++i)
+                if (d->n[i] % 128 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear: qkv_rope segments are heads x 128 rows");
+        }
         int N = 0;
         for (int i = 0; i < d->n_seg; ++i) {
             if (!d->w[i] || d->n[i] < 1) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: segment %d", i);
@@ -424,7 +486,7 @@ int make_plan(const ls_linear_desc* d, Plan& pl) {
     const int groups = (rows + 63) / 64;
     // more than 32 token rows run ONE workgroup per CU (512 registers per wave): give it 128 weight rows when that
     // still fills the chip -- half the x staging traffic, half the workgroups (measured: lm_head 230 -> 209 us)
-    pl.NT = (pl.MT >= 5 && groups >= 2 * 224) ? 8 : 4;
+    pl.NT = (pl.MT >= 5 && groups >= 2 * 224 && d->epilogue != LS_EPI_QKV_ROPE) ? 8 : 4;
     pl.nslabs = (rows + pl.NT * 16 - 1) / (pl.NT * 16);
     pl.nks = d->K / 32;
     pl.S = pick_splits(groups, pl.nks, d->n_splits);
@@ -458,6 +520,15 @@ int launch_mt(const GemmK& k, const Plan& pl, hipStream_t s) {
     }
 }
 
+template <typename E, int EPI>
+int launch_mt4(const GemmK& k, const Plan& pl, hipStream_t s) {      // epilogues that only exist with 4-tile slabs
+    switch (pl.MT) {
+        case 1: return launch<E, 1, 4, EPI>(k, pl, s);
+        case 2: return launch<E, 2, 4, EPI>(k, pl, s);
+        default: return launch<E, 5, 4, EPI>(k, pl, s);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -467,7 +538,8 @@ size_t ls_linear_packed_bytes(int N, int K) {
     return (size_t)((N + 63) / 64) * 64 * (size_t)K * 2;
 }
 
-static int pack_impl(const void* w, const void* w_up, void* packed, int N, int K, int dtype, void* stream, const char* what) {
+static int pack_impl(const void* w, const void* w_up, void* packed, int N, int K, int dtype, void* stream, const char* what,
+                     int rope = 0) {
     if (!w || !packed) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null pointer", what);
     if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "%s: dtype", what);
     if (N < 1 || K < 32 || K % 32 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: K=%d must be a multiple of 32", what, K);
@@ -477,7 +549,7 @@ static int pack_impl(const void* w, const void* w_up, void* packed, int N, int K
     if (grid > 65535 * 4) grid = 65535 * 4;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const uint16_t*>(w), static_cast<const uint16_t*>(w_up), static_cast<uint16_t*>(packed), N, K,
-                       nblocks);
+                       nblocks, rope);
     LS_CHECK_LAUNCH("pack_weight_kernel");
     return LS_OK;
 }
@@ -490,6 +562,11 @@ int ls_linear_pack_gate_up(const void* gate_weight, const void* up_weight, void*
     if (!up_weight) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear_pack_gate_up: null pointer");
     if (N % 16 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear_pack_gate_up: N %% 16");
     return pack_impl(gate_weight, up_weight, packed, N, K, dtype, stream, "ls_linear_pack_gate_up");
+}
+
+int ls_linear_pack_rope(const void* weight, void* packed, int N, int K, int dtype, void* stream) {
+    if (N % 128 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear_pack_rope: N must be heads x 128 rows");
+    return pack_impl(weight, nullptr, packed, N, K, dtype, stream, "ls_linear_pack_rope", 1);
 }
 
 size_t ls_linear_workspace_bytes(const ls_linear_desc* d) {
@@ -523,12 +600,19 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
     k.S = pl.S;
     k.nslabs = pl.nslabs;
     k.flag_off = (int)pl.lds - 16;
+    k.rope_cos = static_cast<const char*>(d->rope_cos);
+    k.rope_sin = static_cast<const char*>(d->rope_sin);
+    k.rope_segs = d->n_seg < 2 ? d->n_seg : 2;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     if (d->dtype == LS_F16)
-        rc = d->epilogue == LS_EPI_SILU_MUL ? launch_mt<ElemF16, EPI_SILU_MUL>(k, pl, s) : launch_mt<ElemF16, EPI_NONE>(k, pl, s);
+        rc = d->epilogue == LS_EPI_SILU_MUL   ? launch_mt<ElemF16, EPI_SILU_MUL>(k, pl, s)
+             : d->epilogue == LS_EPI_QKV_ROPE ? launch_mt4<ElemF16, EPI_QKV_ROPE>(k, pl, s)
+                                              : launch_mt<ElemF16, EPI_NONE>(k, pl, s);
     else
-        rc = d->epilogue == LS_EPI_SILU_MUL ? launch_mt<ElemBF16, EPI_SILU_MUL>(k, pl, s) : launch_mt<ElemBF16, EPI_NONE>(k, pl, s);
+        rc = d->epilogue == LS_EPI_SILU_MUL   ? launch_mt<ElemBF16, EPI_SILU_MUL>(k, pl, s)
+             : d->epilogue == LS_EPI_QKV_ROPE ? launch_mt4<ElemBF16, EPI_QKV_ROPE>(k, pl, s)
+                                              : launch_mt<ElemBF16, EPI_NONE>(k, pl, s);
     if (d->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s);
     return rc;
 }

@@ -90,16 +90,19 @@ class DecodeLinear(nn.Linear):
     def __init__(self, in_features, out_features, bias=True, ops=None):
         super().__init__(in_features, out_features, bias=bias)
         self.ops = ops
-        self._packed = None
+        self._packed = {}
         self._packed_key = None
 
-    def packed(self):
+    def packed(self, rope: bool = False):
+        """The streamed copy of the weight; ``rope=True``: the q/k layout of ``ops.linear_qkv_rope``."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.dtype, w.device)
         if self._packed_key != key:
-            self._packed = self.ops.pack_weight(w)
+            self._packed = {}
             self._packed_key = key
-        return self._packed
+        if rope not in self._packed:
+            self._packed[rope] = self.ops.pack_weight(w, rope=True) if rope else self.ops.pack_weight(w)
+        return self._packed[rope]
 
     def streams(self, x) -> bool:
         return self.ops is not None and self.ops.linear_supported(x, self.in_features)
@@ -152,12 +155,32 @@ class LlamaMLP(nn.Module):
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
-def project_qkv(ops, x, q_proj, k_proj, v_proj):
-    """q/k/v projections of one input: one launch over the three packed weights when the input is decode-shaped
-    (the outputs are then column slices of one [rows, Nq+Nk+Nv] buffer), three plain linears otherwise."""
-    if q_proj.streams(x) and all(m.out_features % 128 == 0 for m in (q_proj, k_proj, v_proj)):
-        return ops.linear_multi(x, [q_proj.packed(), k_proj.packed(), v_proj.packed()], [q_proj.bias, k_proj.bias, v_proj.bias])
-    return q_proj(x), k_proj(x), v_proj(x)
+FUSE_QKV_ROPE = True      # decode-shaped q|k|v projections rotate q and k in the GEMM epilogue (tools/ab_round.py flips it)
+
+
+def project_qkv(ops, x, q_proj, k_proj, v_proj, position_embeddings, num_heads, num_kv_heads, head_dim=128):
+    """q/k/v projections + rotary embedding of q and k (``llama.py:371-378``): [bsz, q_len, heads, head_dim] each.
+    Decode-shaped input: ONE launch over the three packed weights with the rotation in its epilogue (the outputs are
+    column slices of one [rows, Nq+Nk+Nv] buffer); otherwise three plain linears and ``rope_apply_``.
+    ``k_proj`` None: q only (the draft's cross-attention)."""
+    bsz, q_len, _ = x.shape
+    cos, sin = position_embeddings
+    projs = [p for p in (q_proj, k_proj, v_proj) if p is not None]
+    streams = q_proj.streams(x) and all(m.out_features % 128 == 0 for m in projs)
+    fused = streams and head_dim == 128 and FUSE_QKV_ROPE
+    if fused:
+        packed = [m.packed(rope=i < 2) for i, m in enumerate(projs)]
+        outs = ops.linear_qkv_rope(x, packed, [m.bias for m in projs], cos, sin)
+    elif streams:
+        outs = ops.linear_multi(x, [m.packed() for m in projs], [m.bias for m in projs])
+    else:
+        outs = [m(x) for m in projs]
+    q = outs[0].view(bsz, q_len, num_heads, head_dim)
+    k = outs[1].view(bsz, q_len, num_kv_heads, head_dim) if k_proj is not None else q[:, :, :0]
+    v = outs[2].view(bsz, q_len, num_kv_heads, head_dim) if v_proj is not None else None
+    if not fused:
+        ops.rope_apply_(q, k, cos, sin)
+    return q, k, v
 
 
 def chunked_causal_prefill(ops, q, k, v, k_cache, v_cache, window_left=-1):
@@ -196,14 +219,8 @@ class LlamaAttention(nn.Module):
         self.shard = None                                # dist.KVShard when the prefix KV is sequence-sharded
 
     def _qkv(self, hidden_states, position_embeddings):
-        bsz, q_len, _ = hidden_states.size()
-        q, k, v = project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj)
-        q = q.view(bsz, q_len, self.num_heads, self.head_dim)
-        k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-        v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-        cos, sin = position_embeddings
-        self.ops.rope_apply_(q, k, cos, sin)
-        return q, k, v
+        return project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj, position_embeddings,
+                           self.num_heads, self.num_key_value_heads, self.head_dim)
 
     def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, tree_mask=None,
                 exec_type="training", induction_head=False, tree_mask_bits=None):

@@ -70,18 +70,12 @@ class GlideAttention(nn.Module):
         return y
 
     def _qkv(self, hidden_states, position_embeddings, need_kv=True):
-        bsz, q_len, _ = hidden_states.size()
-        cos, sin = position_embeddings
         if need_kv:
-            q, k, v = project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj)
-            q = q.view(bsz, q_len, self.num_heads, self.head_dim)
-            k = k.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-            v = v.view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-            self.ops.rope_apply_(q, k, cos, sin)
-            return q, k, v
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+            return project_qkv(self.ops, hidden_states, self.q_proj, self.k_proj, self.v_proj, position_embeddings,
+                               self.num_heads, self.num_key_value_heads, self.head_dim)
         # cross-attention: the reference projects k/v it never uses (:248-249 vs :265); skip them
-        self.ops.rope_apply_(q, q[:, :, :0], cos, sin)
+        q, _, _ = project_qkv(self.ops, hidden_states, self.q_proj, None, None, position_embeddings,
+                              self.num_heads, self.num_key_value_heads, self.head_dim)
         return q, None, None
 
     def _cross(self, q, K_Cache, V_Cache, llm_kv_len, causal: bool):

@@ -98,13 +98,14 @@ class PackedWeight:
     """An ``nn.Linear.weight`` [N, K] re-laid-out once by ``ls_linear_pack_weight`` into the MFMA A-operand
     order the skinny kernel streams (include/longspec_hip.h).  ``data`` is a flat tensor of the weight's
     dtype with ceil(N/16)*16*K elements."""
-    __slots__ = ("data", "n", "k", "dtype")
+    __slots__ = ("data", "n", "k", "dtype", "rope")
 
     def __init__(self, data, n, k):
-        self.data, self.n, self.k, self.dtype = data, n, k, data.dtype
+        self.data, self.n, self.k, self.dtype, self.rope = data, n, k, data.dtype, False
 
 
-def pack_weight(weight: torch.Tensor) -> PackedWeight:
+def pack_weight(weight: torch.Tensor, rope: bool = False) -> PackedWeight:
+    """``rope=True``: a q_proj / k_proj weight [heads*128, K] for ``linear_qkv_rope`` (rotary pairs in neighbouring tiles)."""
     _dev(weight)
     if weight.dim() != 2 or weight.shape[1] % 32 != 0:
         raise ValueError("pack_weight: [N, K] weight with K a multiple of 32 expected")
@@ -113,8 +114,13 @@ def pack_weight(weight: torch.Tensor) -> PackedWeight:
     lib = _C.load()
     nbytes = lib.ls_linear_packed_bytes(N, K)
     out = torch.empty(nbytes // 2, dtype=w.dtype, device=w.device)
-    _C.check(lib.ls_linear_pack_weight(w.data_ptr(), out.data_ptr(), N, K, _dtype(w), _stream()), "ls_linear_pack_weight")
-    return PackedWeight(out, N, K)
+    if rope:
+        _C.check(lib.ls_linear_pack_rope(w.data_ptr(), out.data_ptr(), N, K, _dtype(w), _stream()), "ls_linear_pack_rope")
+    else:
+        _C.check(lib.ls_linear_pack_weight(w.data_ptr(), out.data_ptr(), N, K, _dtype(w), _stream()), "ls_linear_pack_weight")
+    pw = PackedWeight(out, N, K)
+    pw.rope = rope
+    return pw
 
 
 def pack_gate_up(gate_weight: torch.Tensor, up_weight: torch.Tensor) -> PackedWeight:
@@ -188,7 +194,7 @@ def set_linear_timing(hook):
     _linear_timing = hook
 
 
-def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
+def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None):
     _dev(x)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -203,6 +209,8 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
             raise TypeError("linear: weights must be PackedWeight (ops.pack_weight(nn.Linear.weight))")
         if w.k != K or w.dtype != x.dtype:
             raise ValueError(f"packed weight [{w.n}, {w.k}] {w.dtype} does not match x [..., {K}] {x.dtype}")
+        if w.rope != (epilogue == _C.LS_EPI_QKV_ROPE and i < 2):
+            raise ValueError("linear: q/k weights of linear_qkv_rope are packed with rope=True, every other weight without")
         d.w[i] = w.data.data_ptr()
         b = biases[i] if biases is not None else None
         if b is not None and (b.dtype != x.dtype or not b.is_contiguous() or b.numel() != w.n):
@@ -219,6 +227,13 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None):
     d.epilogue = epilogue
     d.n_splits = n_splits
     d.ldx, d.ldy = x2.stride(0), n_out
+    if rope is not None:
+        cos, sin = rope
+        _dev(cos, sin)
+        for t in (cos, sin):
+            if t.dtype != x.dtype or not t.is_contiguous() or t.numel() != M * 128:
+                raise ValueError("linear_qkv_rope: cos/sin must be contiguous [rows, 128] tables of x's dtype")
+        d.rope_cos, d.rope_sin = cos.data_ptr(), sin.data_ptr()
     if timing is None and _linear_timing is not None:
         rows_w = sum(w.n for w in weights) * (2 if epilogue == _C.LS_EPI_SILU_MUL else 1)
         timing = _linear_timing((rows_w * K + M * K + M * n_out) * x.element_size())
@@ -245,6 +260,20 @@ def linear_multi(x: torch.Tensor, weights, biases=None, n_splits: int = 0, timin
     weights = list(weights)
     biases = list(biases) if biases is not None else [None] * len(weights)
     y = _linear_call(x, weights, biases, _C.LS_EPI_NONE, n_splits, timing)
+    outs, o = [], 0
+    for w in weights:
+        outs.append(y[:, o:o + w.n].unflatten(0, x.shape[:-1]))
+        o += w.n
+    return outs
+
+
+def linear_qkv_rope(x: torch.Tensor, weights, biases, cos: torch.Tensor, sin: torch.Tensor, n_splits: int = 0, timing=None):
+    """``apply_rotary_pos_emb(q_proj(x), k_proj(x), cos, sin)`` and ``v_proj(x)`` (``llama.py:371-378``) in ONE launch:
+    the rotation runs in the projection's epilogue on the rounded outputs, with the roundings of ``rope_apply_``.
+    ``weights`` = [q] or [q, k] or [q, k, v] (q, k packed with ``rope=True``); cos/sin [rows, 128]."""
+    weights = list(weights)
+    biases = list(biases) if biases is not None else [None] * len(weights)
+    y = _linear_call(x, weights, biases, _C.LS_EPI_QKV_ROPE, n_splits, timing, rope=(cos, sin))
     outs, o = [], 0
     for w in weights:
         outs.append(y[:, o:o + w.n].unflatten(0, x.shape[:-1]))

@@ -91,6 +91,41 @@ def test_qkv_in_one_launch(M):
         _check(o.cpu(), ref_ops.linear(x, w, b), _acc_tol(x, w))
 
 
+@pytest.mark.parametrize("dims", [(4096, 1024, 4096), (512, 128, 256), (5120, 5120, 5120), (1024, 256, 896)],
+                         ids=lambda d: "x".join(map(str, d)))
+@pytest.mark.parametrize("M", [1, 6, 16, 30, 74, 80])
+@pytest.mark.parametrize("dtype,bias", [(torch.float16, False), (torch.float16, True), (torch.bfloat16, True)],
+                         ids=["f16", "f16_bias", "bf16_bias"])
+def test_qkv_rope_in_one_launch(dims, M, dtype, bias):
+    """q|k|v projection with apply_rotary_pos_emb in the epilogue == the unfused launch followed by rope_apply_,
+    bit for bit (same accumulation order, same roundings); the unfused pair is checked against the oracle above
+    and in test_gpu_ops."""
+    from longspec_amd import ops
+    Nq, Nkv, K = dims
+    x = _mk((1, M, K), 1, dtype=dtype).cuda()
+    ws = [_mk((n, K), 2 + i, K ** -0.5, dtype=dtype).cuda() for i, n in enumerate((Nq, Nkv, Nkv))]
+    bs = [_mk((n,), 7 + i, 0.5, dtype=dtype).cuda() if bias else None for i, n in enumerate((Nq, Nkv, Nkv))]
+    pos = torch.arange(1000, 1000 + M)[None]
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, 128, 2).float() / 128))
+    cos, sin = ops.rope_cos_sin(pos.cuda(), inv_freq.cuda(), 1.0, dtype)
+    q0, k0, v0 = ops.linear_multi(x, [ops.pack_weight(w) for w in ws], bs)
+    q0 = q0.reshape(1, M, Nq // 128, 128).clone()
+    k0 = k0.reshape(1, M, Nkv // 128, 128).clone()
+    ops.rope_apply_(q0, k0, cos, sin)
+    q1, k1, v1 = ops.linear_qkv_rope(x, [ops.pack_weight(w, rope=i < 2) for i, w in enumerate(ws)], bs, cos, sin)
+    assert torch.equal(q1.reshape(q0.shape), q0) and torch.equal(k1.reshape(k0.shape), k0) and torch.equal(v1, v0)
+    # q alone (the draft's cross-attention); its split-K factor is that of the q weight alone
+    q3 = ops.linear(x, ops.pack_weight(ws[0]), bs[0]).reshape(q0.shape).clone()
+    ops.rope_apply_(q3, q3[:, :, :0], cos, sin)
+    (q2,) = ops.linear_qkv_rope(x, [ops.pack_weight(ws[0], rope=True)], bs[:1], cos, sin)
+    assert torch.equal(q2.reshape(q0.shape), q3)
+    # the layouts are not interchangeable
+    with pytest.raises(ValueError):
+        ops.linear_qkv_rope(x, [ops.pack_weight(w) for w in ws], bs, cos, sin)
+    with pytest.raises(ValueError):
+        ops.linear_multi(x, [ops.pack_weight(w, rope=True) for w in ws], bs)
+
+
 @pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512)])
 @pytest.mark.parametrize("M", [1, 16, 30, 74])
 def test_mlp_gate_up_silu(N, K, M):
