@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--cpu-sample-calls", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
+    ap.add_argument("--shard-path", action="store_true",
+                    help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
+                         "with one rank, to price its extra launches without a second GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,9 +216,14 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.shard_path:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     cfg = make_config(args.model)
     H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
@@ -228,7 +236,7 @@ def main():
     m.set_max_gen_len(max_rows)
     m.glide.set_max_gen_len(max_rows)
     synth_kv(m, Ls, L_total, max_rows, device, seed=4321 + rank)
-    if world > 1:
+    if world > 1 or args.shard_path:
         from longspec_amd.dist import KVShard
         shard = KVShard(rank, world, shard_rows=Ls)
         for layer in m.model.layers:
@@ -263,8 +271,8 @@ def main():
             pool.on = gpool.on = True
         t0 = time.time()
         for i in range(args.steps):
-            if gpool is not None:                        # GEMM launches are bracketed on every 5th round only: two event
-                gpool.on = (i % 5 == 0)                  # records around each of ~160 launches/round would cost ~1 ms/round
+            if gpool is not None:                        # launches are bracketed on every 5th round only: two event
+                gpool.on = pool.on = (i % 5 == 0)        # records around each of ~200 launches/round would cost ~1 ms/round
             m.tree_round(st)
         barrier()
         elapsed = time.time() - t0
@@ -352,7 +360,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, Ls, args.cpu_sample_calls, tau)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.shard_path:
         dist.barrier()
         dist.destroy_process_group()
 
