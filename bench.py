@@ -193,6 +193,9 @@ def cpu_baseline(cfg, L, sample_calls, tau):
                       f"measured tau"}
 
 
+SAMPLE = 10      # every SAMPLE-th timed round is issued launch by launch with HIP events around the roofline kernels
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +208,7 @@ def main():
     ap.add_argument("--cpu-sample-calls", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
+    ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
                          "with one rank, to price its extra launches without a second GPU")
@@ -253,7 +257,7 @@ def main():
         torch.cuda.synchronize()
 
     pool = EventPool(cfg.num_hidden_layers * args.steps) if rank == 0 else None
-    gpool = GemmPool((4 * cfg.num_hidden_layers + 48) * (args.steps // 5 + 1)) if rank == 0 else None
+    gpool = GemmPool((4 * cfg.num_hidden_layers + 48) * (args.steps // SAMPLE + 1)) if rank == 0 else None
     if pool is not None:
         from longspec_amd import ops as _ops
         for layer in m.model.layers:
@@ -263,6 +267,10 @@ def main():
     with torch.inference_mode():
         st = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
         st.eos = None                                    # run a fixed number of rounds
+        graphs = st.use_graphs and not args.no_graphs
+        st.use_graphs = graphs
+        if graphs:
+            m.prepare_tree_graphs(st)                    # one HIP graph per accepted-token count, captured before the clock starts
         for _ in range(args.warmup):
             m.tree_round(st)
         barrier()
@@ -271,8 +279,9 @@ def main():
             pool.on = gpool.on = True
         t0 = time.time()
         for i in range(args.steps):
-            if gpool is not None:                        # launches are bracketed on every 5th round only: two event
-                gpool.on = pool.on = (i % 5 == 0)        # records around each of ~200 launches/round would cost ~1 ms/round
+            if gpool is not None:                        # launches are bracketed on every 10th round only: two event
+                gpool.on = pool.on = (i % SAMPLE == 0)   # records around each of ~200 launches cost ~2 ms per round
+                st.use_graphs = graphs and not pool.on   # the bracketed rounds are issued launch by launch, the others replayed
             m.tree_round(st)
         barrier()
         elapsed = time.time() - t0
@@ -297,6 +306,7 @@ def main():
                    "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
                    "parallelism": "1 GPU" if world == 1 else f"prefix KV sequence-sharded x{world}, weights replicated"},
         "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
+        "hip_graphs": bool(graphs and st.graphs is not False),
     }
 
     if rank == 0:
@@ -318,7 +328,7 @@ def main():
                                      "verify pass and the 5 draft passes)",
                            "algorithmic_bytes_per_launch": round(gs["bytes"] / gs["launches"]),
                            "avg_launch_us": round(gs["us"] / gs["launches"], 2), "launches_timed": gs["launches"],
-                           "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, 5)) / 1e3, 3),
+                           "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, SAMPLE)) / 1e3, 3),
                            "launches_over_100MB_gbps": round(gs["big_gbps"], 1) if gs["big_gbps"] else None}
         # ---- second kernel: hybrid verification attention, stage 1 (this rank's KV shard) ---------------------------
         mean_us = pool.mean_us()
@@ -340,18 +350,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_vanilla:
         # ---- speed-up denominator: vanilla autoregressive decode on the same model and prefix ----------
         with torch.inference_mode():
-            cl = lens.clone()
-            tokv = first.view(1, 1).clone()
             for layer in m.model.layers:
                 layer.self_attn.timing = None
-            m._set_hints(L_total + args.vanilla_steps + 8, L_total + 8)
-            for i in range(args.vanilla_steps + 2):
-                if i == 2:
+            out_v = torch.zeros((1, args.vanilla_steps + 8), dtype=torch.int64, device=device)
+            out_v[:, 0] = first
+            vs = m.begin_vanilla_decode(out_v, lens.clone(), lens.clone(), L_total)
+            vs.use_graphs = vs.use_graphs and not args.no_graphs          # same treatment as the tree rounds
+            for i in range(args.vanilla_steps + 4):                       # steps 1-2 eager, 3 captures, the rest replay
+                if i == 4:
                     torch.cuda.synchronize()
                     tv = time.time()
-                hs = m.model.forward(tokv, cache_lens=cl.clone(), exec_type="decoding").last_hidden_state
-                tokv = m.lm_head(hs[:, -1, :]).argmax(dim=-1).view(1, 1)
-                cl += 1
+                m.vanilla_step(vs)
             torch.cuda.synchronize()
             vanilla_tps = args.vanilla_steps / (time.time() - tv)
         out["vanilla_tokens_per_s"] = round(vanilla_tps, 3)

@@ -259,11 +259,13 @@ int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const
 /* End of the round (llama_glide.py:1093-1121): output_ids[z, emitted + j] = acc_ids[z, j] (j < acc_num);
  * state[z] = (acc_num, any(output_ids[z, :out_cap] == eos)) for the round's single host read; the tree
  * state reset (tree_mask = 0, column 0 = 1; all_spec = 0, all_spec[0] = last accepted id; logp_sum = 0);
- * target_lens [b] int32 += target_add and draft_kv_lens [b] int32 += acc_num (both nullable). */
+ * target_lens [b] int32 += target_add and draft_kv_lens [b] int32 += acc_num (both nullable).
+ * emitted_dev [b] int32 (nullable): when given, the write offset is read from it instead of `emitted` and
+ * advanced by acc_num -- a round replayed from a HIP graph carries no host-side integers. */
 int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int max_acc, int64_t* output_ids,
-                   int64_t out_stride, int out_cap, int emitted, int has_eos, int64_t eos, int64_t* state,
-                   int64_t* tree_mask, int64_t* all_spec, float* logp_sum, int F, int32_t* target_lens,
-                   int target_add, int32_t* draft_kv_lens, void* stream);
+                   int64_t out_stride, int out_cap, int emitted, int32_t* emitted_dev, int has_eos, int64_t eos,
+                   int64_t* state, int64_t* tree_mask, int64_t* all_spec, float* logp_sum, int F,
+                   int32_t* target_lens, int target_add, int32_t* draft_kv_lens, void* stream);
 
 /* `embed_tokens(ids)` of a short pass (llama.py:579, llama_glide.py:1003,1030): out [n,hidden] =
  * table[ids] (table [vocab,hidden] dtype, ids int64 inside the vocabulary). */

@@ -219,13 +219,15 @@ __global__ __launch_bounds__(TT) void tree_collapse_kernel(
 // (:1098-1102) and the length bookkeeping (:1104-1117), behind ONE host read of state[z] = (acc_num, eos hit).
 __global__ __launch_bounds__(TT) void tree_commit_kernel(const int64_t* __restrict__ acc_ids, const int64_t* __restrict__ acc_num,
                                                          int max_acc, int64_t* __restrict__ output_ids, long out_stride,
-                                                         int out_cap, int emitted, int has_eos, int64_t eos,
+                                                         int out_cap, int emitted_arg, int32_t* emitted_dev, int has_eos,
+                                                         int64_t eos,
                                                          int64_t* __restrict__ state, int64_t* __restrict__ tree_mask,
                                                          int64_t* __restrict__ all_spec, float* __restrict__ logp_sum, int F,
                                                          int32_t* target_lens, int target_add, int32_t* draft_kv_lens) {
     __shared__ int s_hit;
     const int z = blockIdx.x, tid = threadIdx.x;
     const int n = (int)acc_num[z];
+    const int emitted = emitted_dev ? emitted_dev[z] : emitted_arg;       // device-side counter: graph replays carry no host ints
     int64_t* out = output_ids + (long)z * out_stride;
     if (tid == 0) s_hit = 0;
     if (tid < max_acc && tid < n && emitted + tid < out_cap) out[emitted + tid] = acc_ids[(long)z * max_acc + tid];
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(TT) void tree_commit_kernel(const int64_t* __restri
         state[2 * z + 1] = s_hit;
         if (target_lens) target_lens[z] += target_add;
         if (draft_kv_lens) draft_kv_lens[z] += n;
+        if (emitted_dev) emitted_dev[z] = emitted + n;
     }
 }
 
@@ -315,16 +318,16 @@ int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const
 }
 
 int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int max_acc, int64_t* output_ids,
-                   int64_t out_stride, int out_cap, int emitted, int has_eos, int64_t eos, int64_t* state, int64_t* tree_mask,
-                   int64_t* all_spec, float* logp_sum, int F, int32_t* target_lens, int target_add, int32_t* draft_kv_lens,
-                   void* stream) {
+                   int64_t out_stride, int out_cap, int emitted, int32_t* emitted_dev, int has_eos, int64_t eos, int64_t* state,
+                   int64_t* tree_mask, int64_t* all_spec, float* logp_sum, int F, int32_t* target_lens, int target_add,
+                   int32_t* draft_kv_lens, void* stream) {
     if (!acc_ids || !acc_num || !output_ids || !state || !tree_mask || !all_spec)
         LS_FAIL(LS_ERR_INVALID_ARG, "tree_commit: null pointer");
     if (b < 1 || F < 1 || F > MAXF || max_acc < 1 || max_acc > TT || out_cap < 1 || emitted < 0)
         LS_FAIL(LS_ERR_INVALID_ARG, "tree_commit: F=%d max_acc=%d out_cap=%d emitted=%d", F, max_acc, out_cap, emitted);
     hipLaunchKernelGGL(tree_commit_kernel, dim3(b), dim3(TT), 0, static_cast<hipStream_t>(stream), acc_ids, acc_num, max_acc,
-                       output_ids, (long)out_stride, out_cap, emitted, has_eos, eos, state, tree_mask, all_spec, logp_sum, F,
-                       target_lens, target_add, draft_kv_lens);
+                       output_ids, (long)out_stride, out_cap, emitted, emitted_dev, has_eos, eos, state, tree_mask, all_spec,
+                       logp_sum, F, target_lens, target_add, draft_kv_lens);
     LS_CHECK_LAUNCH("tree_commit_kernel");
     return LS_OK;
 }

@@ -197,6 +197,8 @@ class LlamaGlide(LlamaForCausalLM):
             p.requires_grad = False
         self.eval()
 
+    GRAPH_ROUNDS = True      # capture tree rounds into HIP graphs (one per accepted-token count), see tree_round
+
     # ------------------------------------------------------------------------------------------
     def set_max_gen_len(self, max_gen_len):
         super().set_max_gen_len(max_gen_len)
@@ -239,14 +241,10 @@ class LlamaGlide(LlamaForCausalLM):
         eos = self._stop_id(eos_id, "vanilla")
         _sync(input_ids)
         start_time = time.time()
+        vs = self.begin_vanilla_decode(output_ids, cache_lens, input_len.int(), P)
         for step in range(1, max_gen_len):
-            self._set_hints(P + step, P + step)
-            cur = output_ids[rows, (cache_lens - input_len).long()].view(bsz, -1)
-            hidden_states = self.model.forward(cur, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
-            llm_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -1, :]))
-            cache_lens += 1
+            self.vanilla_step(vs)
             num += bsz
-            output_ids[rows, (cache_lens - input_len).long()] = llm_output.view(-1)
             if eos is not None and (step % 16 == 0 or step == max_gen_len - 1):
                 if bool((output_ids[:, :step + 1].eq(eos)).any()):
                     break
@@ -255,6 +253,58 @@ class LlamaGlide(LlamaForCausalLM):
         if eos is not None:
             output_ids, num = _truncate_after_eos_vanilla(output_ids, num, eos, bsz)
         return output_ids, num, elapsed_time
+
+    # ------------------------------------------------------------------------------------------
+    def begin_vanilla_decode(self, output_ids, cache_lens, input_len, prompt_bound: int):
+        """State of the vanilla loop (``llama_glide.py:566-583``): ``output_ids`` [bsz, max_gen] with the first
+        token in place, ``cache_lens`` [bsz] int32 valid rows of every cache, ``input_len`` [bsz] int32."""
+        from types import SimpleNamespace
+        dev = output_ids.device
+        vs = SimpleNamespace(output_ids=output_ids, cache_lens=cache_lens, input_len=input_len, P=prompt_bound, step=0,
+                             rows=torch.arange(output_ids.size(0), device=dev), graph=None, graph_stream=None)
+        vs.use_graphs = bool(dev.type == "cuda" and self.model.layers[-1].self_attn.shard is None and self.GRAPH_ROUNDS)
+        return vs
+
+    def _vanilla_device(self, vs):
+        """One token, device work only: the step has no host-side parameter at all."""
+        out, cl, il, rows = vs.output_ids, vs.cache_lens, vs.input_len, vs.rows
+        cur = out[rows, (cl - il).long()].view(out.size(0), -1)
+        hidden_states = self.model.forward(cur, cache_lens=cl, exec_type="decoding").last_hidden_state
+        llm_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -1, :]))
+        cl += 1
+        out[rows, (cl - il).long()] = llm_output.view(-1)
+
+    def vanilla_step(self, vs):
+        """Decode one token.  On a GPU the step is captured into a HIP graph after two eager steps and replayed."""
+        vs.step += 1
+        if vs.use_graphs:
+            try:
+                if vs.graph is None and vs.step > 2:
+                    self._set_hints(vs.P + vs.output_ids.size(1), vs.P + vs.output_ids.size(1))
+                    cur = torch.cuda.current_stream()
+                    vs.graph_stream = torch.cuda.Stream()
+                    vs.graph_stream.wait_stream(cur)
+                    with torch.cuda.stream(vs.graph_stream):          # warm the capture stream's workspaces
+                        self._vanilla_device(vs)
+                    cur.wait_stream(vs.graph_stream)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=vs.graph_stream):
+                        self._vanilla_device(vs)
+                    vs.graph = (graph, self.ops.workspace_tensors() if hasattr(self.ops, "workspace_tensors") else None)
+                    return                                            # the warm-up step was this call's token
+                if vs.graph is not None:
+                    vs.graph[0].replay()
+                    return
+            except Exception as e:
+                if torch.cuda.is_current_stream_capturing():
+                    raise
+                import warnings
+                warnings.warn(f"HIP-graph capture of the vanilla step failed ({type(e).__name__}: {e}); running eagerly")
+                vs.use_graphs = False
+                if vs.graph_stream is not None:                       # the warm-up step already produced this token
+                    return
+        self._set_hints(vs.P + vs.step, vs.P + vs.step)
+        self._vanilla_device(vs)
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
@@ -446,9 +496,16 @@ class LlamaGlide(LlamaForCausalLM):
         st.count, st.num = 0, bsz
         st.all_spec = torch.zeros((bsz, Fn), dtype=torch.int64, device=dev)
         st.all_spec[:, 0] = first_token
-        st.acc_ids = first_token.view(bsz, 1).clone()
+        st.acc_pad = torch.zeros((bsz, gamma + 1), dtype=torch.int64, device=dev)     # accepted ids of the last round
+        st.acc_pad[:, 0] = first_token
+        st.acc_ids = st.acc_pad[:, :1]
         st.a = 1                              # host mirror of acc_num (G9: the pad id is outside the vocab)
-        st.emitted = 1                        # tokens written to output_ids so far
+        st.emitted = 1                        # tokens written to output_ids so far (host mirror of emitted_dev)
+        st.emitted_dev = torch.ones((bsz,), dtype=torch.int32, device=dev)
+        # HIP graphs of the round, one per `a`: on a GPU, without a KV shard (a collective inside a captured round is
+        # not something this build could test) -- callers that bracket kernels with events switch it off per round
+        st.use_graphs = bool(dev.type == "cuda" and self.model.layers[-1].self_attn.shard is None and self.GRAPH_ROUNDS)
+        st.graphs, st.graph_stream, st.graph_pool = {}, None, None
         st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
         st.tree_mask[:, :, 0] = 1
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
@@ -459,18 +516,121 @@ class LlamaGlide(LlamaForCausalLM):
     def tree_round(self, st) -> bool:
         """One draft-then-verify round (``llama_glide.py:997-1121``): 1 + (gamma-1) draft passes growing
         the beam tree, one R-row target pass, accept/collapse.  Returns False when generation must stop.
+
+        Everything between two host reads is device work whose only host-side parameter is ``a``, the number of
+        tokens accepted by the previous round (1..gamma+1).  With ``st.use_graphs`` the round is captured once per
+        value of ``a`` into a HIP graph and replayed: the ~370 launches of a round (most of them 4-20 us draft
+        kernels the host cannot issue fast enough) become one."""
+        a = st.a
+        state = None
+        if st.use_graphs:
+            state = self._graph_round(st, a)
+        if state is None:
+            # host bounds: no cache holds more than P + emitted (+ this round's speculative rows) valid rows
+            self._set_hints(st.P + st.emitted + st.R, st.P + st.emitted + st.Fn)
+            state = self._round_device(st, a)
+        state = state.tolist()                                        # the round's ONE host read
+        a, hit = state[0][0], any(row[1] for row in state)
+        st.acc_ids = st.acc_pad[:, :a]
+        st.a = a
+        st.emitted += a
+        st.count += a - 1
+        st.num += st.bsz
+        if st.emitted + st.gamma + 2 > st.output_ids.size(1):         # :1118
+            return False
+        if hit:                                                       # :1120
+            return False
+        return True
+
+    def _graph_hints(self, st):
+        # grid bounds of the whole generation, so that a captured round stays valid until the end
+        self._set_hints(st.P + st.output_ids.size(1) + st.R, st.P + st.output_ids.size(1) + st.Fn)
+
+    def _graph_warm(self, st, a: int):
+        """Run the round eagerly ON the capture stream (the operator layer's workspaces are per stream; lazy
+        one-time work -- weight packing, kernel attributes -- must not fall into a capture)."""
+        cur = torch.cuda.current_stream()
+        if st.graph_stream is None:
+            st.graph_stream = torch.cuda.Stream()
+        self._graph_hints(st)
+        st.graph_stream.wait_stream(cur)
+        with torch.cuda.stream(st.graph_stream):
+            state = self._round_device(st, a)
+        cur.wait_stream(st.graph_stream)
+        st.graphs[a] = "warm"
+        return state
+
+    def _graph_capture(self, st, a: int):
+        self._graph_hints(st)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st.graph_stream, pool=st.graph_pool):
+            state = self._round_device(st, a)
+        if st.graph_pool is None:
+            st.graph_pool = graph.pool()
+        # the graph holds raw pointers into the per-stream workspaces of the operator layer
+        keep = self.ops.workspace_tensors() if hasattr(self.ops, "workspace_tensors") else None
+        st.graphs[a] = (graph, state, keep)
+        return st.graphs[a]
+
+    def _graph_round(self, st, a: int):
+        """Replay the HIP graph of a round that starts from ``a`` accepted tokens; the first round with a new ``a``
+        runs eagerly (warm-up), the second one is captured.  Returns the round's state tensor, or None when the
+        round has to run eagerly."""
+        if st.graphs is False:
+            return None
+        try:
+            g = st.graphs.get(a)
+            if g is None:
+                return self._graph_warm(st, a)
+            if g == "warm":
+                g = self._graph_capture(st, a)
+            g[0].replay()
+            return g[1]
+        except Exception as e:          # capture is an optimisation: an environment that cannot do it runs eagerly
+            if torch.cuda.is_current_stream_capturing():
+                raise
+            import warnings
+            warnings.warn(f"HIP-graph capture of the decode round failed ({type(e).__name__}: {e}); running eagerly")
+            st.graphs = False
+            return None
+
+    def prepare_tree_graphs(self, st):
+        """Capture the round graphs of every accepted-token count now instead of on first use (benchmarks: keeps the
+        captures out of the timed region).  The warm-up rounds run on a snapshot of the decode state: they only
+        scribble on cache rows beyond the valid lengths."""
+        if not st.use_graphs or st.graphs is False:
+            return
+        names = ("cache_lens", "target_cache_lens_for_draft", "draft_cache_lens", "tree_mask", "all_spec", "history_logp_sum",
+                 "acc_pad", "output_ids", "emitted_dev")
+        try:
+            for a in range(1, st.gamma + 2):
+                if isinstance(st.graphs.get(a), tuple):
+                    continue
+                if st.graphs.get(a) is None:
+                    snap = {n: getattr(st, n).clone() for n in names}
+                    self._graph_warm(st, a)
+                    for n in names:
+                        getattr(st, n).copy_(snap[n])
+                self._graph_capture(st, a)
+        except Exception as e:
+            if torch.cuda.is_current_stream_capturing():
+                raise
+            import warnings
+            warnings.warn(f"HIP-graph capture of the decode round failed ({type(e).__name__}: {e}); running eagerly")
+            st.graphs = False
+
+    def _round_device(self, st, a: int):
+        """The device work of one round (no host read inside): returns state [bsz, 2] = (acc_num, eos hit).
         The length tensors are passed without the reference's ``.clone()``: their in-place updates (inside
         ``ops.tree_grow`` / ``tree_verify_inputs`` / ``tree_commit``) are ordered behind the kernels that read them on
         the same stream."""
-        cand, acc_n, Fn, gamma, R, dev, bsz = st.cand, st.acc_n, st.Fn, st.gamma, st.R, st.dev, st.bsz
+        cand, acc_n, Fn, gamma, R, bsz = st.cand, st.acc_n, st.Fn, st.gamma, st.R, st.bsz
         tree_mask, all_spec, history_logp_sum = st.tree_mask, st.all_spec, st.history_logp_sum
-        a = st.a
         ops = self.ops
         last_attn = self.model.layers[-1].self_attn
-        # host bounds: no cache holds more than P + emitted (+ this round's speculative rows) valid rows
-        self._set_hints(st.P + st.emitted + R, st.P + st.emitted + Fn)
+        acc_ids = st.acc_pad[:, :a]
         # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
-        hidden_states = self.model.embed_tokens(st.acc_ids)
+        hidden_states = self.model.embed_tokens(acc_ids)
         position_ids = st.arange_g[:, :a] + st.draft_cache_lens[:, None]
         position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
@@ -499,7 +659,7 @@ class LlamaGlide(LlamaForCausalLM):
             position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp_sum, topk_indices,
                                                     vocab_size, lo, mid, base=st.draft_cache_lens, want_next=ms + 1 < gamma)
         # ---- V: one R-row target pass (:1078-1091); `draft_cache_lens += 1` (:1076) rides in the input assembly
-        veri_spec, position_ids, mask_bits = ops.tree_verify_inputs(st.acc_ids, a, all_spec, tree_mask, st.cache_lens, R,
+        veri_spec, position_ids, mask_bits = ops.tree_verify_inputs(acc_ids, a, all_spec, tree_mask, st.cache_lens, R,
                                                                     bump=st.draft_cache_lens, bump_add=1)
         hidden_states = self.model.forward(veri_spec, position_ids=position_ids, cache_lens=st.cache_lens,
                                            exec_type="tree_decoding", tree_mask_bits=mask_bits).last_hidden_state
@@ -515,24 +675,13 @@ class LlamaGlide(LlamaForCausalLM):
         else:
             kv_lens, kc, vc = st.cache_lens, None, None
         acc_pad, acc_num_t, double_input, _ = ops.tree_collapse(all_spec, all_llm_pred, tree_mask, kv_lens, acc_n[-2],
-                                                                gamma + 1, kc, vc, cache_len_add=a - 1)
-        # emitted tokens -> output_ids, the EOS test on the whole buffer as the reference does (:1120, G8), the tree
-        # state reset and `cache_lens += a`, `target_cache_lens_for_draft += acc_num` (:1104-1117): one launch, then
-        # ONE host read for (acc_num, eos flag)
-        state = ops.tree_commit(acc_pad, acc_num_t, st.output_ids, st.emitted, st.eos, tree_mask, all_spec, history_logp_sum,
-                                target_lens=st.cache_lens, target_add=a, draft_kv_lens=st.target_cache_lens_for_draft)
-        state = state.tolist()
-        a, hit = state[0][0], any(row[1] for row in state)
-        st.acc_ids = acc_pad[:, :a]
-        st.a = a
-        st.emitted += a
-        st.count += a - 1
-        st.num += bsz
-        if st.emitted + gamma + 2 > st.output_ids.size(1):            # :1118
-            return False
-        if hit:                                                       # :1120
-            return False
-        return True
+                                                                gamma + 1, kc, vc, cache_len_add=a - 1, out_acc_ids=st.acc_pad)
+        # emitted tokens -> output_ids (at the device-side offset), the EOS test on the whole buffer as the reference
+        # does (:1120, G8), the tree state reset and `cache_lens += a`, `target_cache_lens_for_draft += acc_num`
+        # (:1104-1117): one launch; its result is the round's ONE host read for (acc_num, eos flag)
+        return ops.tree_commit(acc_pad, acc_num_t, st.output_ids, 0, st.eos, tree_mask, all_spec, history_logp_sum,
+                               target_lens=st.cache_lens, target_add=a, draft_kv_lens=st.target_cache_lens_for_draft,
+                               emitted_dev=st.emitted_dev)
 
     # ------------------------------------------------------------------------------------------
     def tree_verification(self, input_ids, output_ids, tree_mask, cache_lens, non_leaf_len):      # :1128-1175

@@ -90,6 +90,13 @@ class _ZeroedWorkspace:
 
 
 _gemm_ws = _ZeroedWorkspace()
+
+
+def workspace_tensors():
+    """The scratch buffers currently handed out (a captured HIP graph keeps them alive: it holds their addresses)."""
+    return list(_ws._buf.values()) + list(_gemm_ws._buf.values())
+
+
 _linear_need = {}            # (shape key) -> workspace bytes of the launch plan
 LINEAR_MAX_ROWS = 80
 
@@ -721,10 +728,12 @@ def tree_verify_inputs(acc_ids, a: int, all_spec, tree_mask, cache_lens, R: int,
 
 
 def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: int, max_acc: int,
-                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None, cache_len_add: int = 0):
+                  k_cache: Optional[torch.Tensor] = None, v_cache: Optional[torch.Tensor] = None, cache_len_add: int = 0,
+                  out_acc_ids: Optional[torch.Tensor] = None):
     """Accept/reject tree collapse + last-layer KV row move, one launch, no host sync.
     Returns (acc_ids [b,max_acc] int64 zero-padded, acc_num [b] int64, double_input [b] int32,
-    index_mapping [b,max_acc] int64, -1 padded).  The moved rows start at ``cache_lens + cache_len_add``."""
+    index_mapping [b,max_acc] int64, -1 padded).  The moved rows start at ``cache_lens + cache_len_add``.
+    ``out_acc_ids``: a persistent [b,max_acc] int64 buffer to write the accepted ids into."""
     _dev(all_spec, all_llm_pred, tree_mask, cache_lens, k_cache, v_cache)
     b, Fn = all_spec.shape
     dev = all_spec.device
@@ -732,7 +741,12 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: i
     pred = all_llm_pred.to(torch.int64).contiguous()
     tm = tree_mask.to(torch.int64).contiguous()
     cl = cache_lens.to(torch.int32).contiguous()
-    acc_ids = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
+    if out_acc_ids is not None:
+        if out_acc_ids.dtype != torch.int64 or tuple(out_acc_ids.shape) != (b, max_acc) or not out_acc_ids.is_contiguous():
+            raise TypeError("tree_collapse: out_acc_ids must be a contiguous int64 [b, max_acc] tensor")
+        acc_ids = out_acc_ids
+    else:
+        acc_ids = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
     acc_num = torch.empty((b,), dtype=torch.int64, device=dev)
     dbl = torch.empty((b,), dtype=torch.int32, device=dev)
     imap = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
@@ -754,19 +768,21 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: i
 
 def tree_commit(acc_ids, acc_num, output_ids, emitted: int, eos: Optional[int], tree_mask, all_spec, logp_sum,
                 target_lens: Optional[torch.Tensor] = None, target_add: int = 0,
-                draft_kv_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+                draft_kv_lens: Optional[torch.Tensor] = None, emitted_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """End of a round (``llama_glide.py:1093-1121``) in one launch: the accepted ids go to
     ``output_ids[:, emitted:]``, the tree state is reset for the next round (mask = root column, all_spec[0] =
     the last accepted id, log-prob sums = 0), ``target_lens += target_add``, ``draft_kv_lens += acc_num``.
-    Returns state [b,2] int64 = (acc_num, whole-buffer EOS hit) -- the round's one host read."""
-    _dev(acc_ids, acc_num, output_ids, tree_mask, all_spec, logp_sum, target_lens, draft_kv_lens)
+    Returns state [b,2] int64 = (acc_num, whole-buffer EOS hit) -- the round's one host read.  ``emitted_dev`` [b]
+    int32: the write offset lives on the device (read instead of ``emitted``, advanced by acc_num)."""
+    _dev(acc_ids, acc_num, output_ids, tree_mask, all_spec, logp_sum, target_lens, draft_kv_lens, emitted_dev)
     b, Fn = _tree_state(tree_mask, all_spec, logp_sum)
     if output_ids.dtype != torch.int64 or output_ids.stride(1) != 1 or not acc_ids.is_contiguous() or acc_ids.dtype != torch.int64:
         raise TypeError("tree_commit: output_ids / acc_ids must be int64 with contiguous rows")
     state = torch.empty((b, 2), dtype=torch.int64, device=all_spec.device)
     lib = _C.load()
     _C.check(lib.ls_tree_commit(acc_ids.data_ptr(), acc_num.data_ptr(), b, acc_ids.shape[1], output_ids.data_ptr(),
-                                output_ids.stride(0), output_ids.shape[1], emitted, 0 if eos is None else 1,
+                                output_ids.stride(0), output_ids.shape[1], emitted, _len_i32(emitted_dev, b, "emitted_dev"),
+                                0 if eos is None else 1,
                                 0 if eos is None else int(eos), state.data_ptr(), tree_mask.data_ptr(), all_spec.data_ptr(),
                                 logp_sum.data_ptr(), Fn, _len_i32(target_lens, b, "target_lens"), target_add,
                                 _len_i32(draft_kv_lens, b, "draft_kv_lens"), _stream()), "ls_tree_commit")

@@ -86,9 +86,13 @@ def tree_verify_inputs(acc_ids, a, all_spec, tree_mask, cache_lens, R, bump=None
 
 
 def tree_commit(acc_ids, acc_num, output_ids, emitted, eos, tree_mask, all_spec, logp_sum, target_lens=None, target_add=0,
-                draft_kv_lens=None):
+                draft_kv_lens=None, emitted_dev=None):
     """llama_glide.py:1093-1121 with the reference's tensor ops."""
     g = acc_ids.shape[1]
+    if emitted_dev is not None:
+        assert emitted_dev.numel() == 1, "the CPU restatement follows the reference: batch 1"
+        emitted = int(emitted_dev[0])
+        emitted_dev += acc_num.to(emitted_dev.dtype)
     sl = output_ids[:, emitted:emitted + g]
     keep = torch.arange(g)[None, :sl.shape[1]] < acc_num[:, None]
     sl.copy_(torch.where(keep, acc_ids[:, :sl.shape[1]], sl))
@@ -111,7 +115,7 @@ def embed_supported(ids, weight):
 
 
 def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache=None, v_cache=None,
-                  cache_len_add=0):
+                  cache_len_add=0, out_acc_ids=None):
     acc_ids, acc_num, dbl, imap = ref_ops.tree_verification(all_spec, all_llm_pred, tree_mask, non_leaf_len)
     if k_cache is not None:
         ref_ops.move_accepted_kv(k_cache, v_cache, cache_lens + cache_len_add, imap)
@@ -122,6 +126,9 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, m
         m = int(acc_num[z])
         pad_ids[z, :m] = acc_ids[z, :m]
         pad_map[z, :m] = imap[z, :m]
+    if out_acc_ids is not None:
+        out_acc_ids.copy_(pad_ids)
+        pad_ids = out_acc_ids
     return pad_ids, acc_num, dbl, pad_map
 
 

@@ -41,11 +41,11 @@ def test_tree_spec_generate_matches_reference(run):
 
         @staticmethod
         def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache=None, v_cache=None,
-                          cache_len_add=0):
+                          cache_len_add=0, out_acc_ids=None):
             trace["mask"].append(tree_mask.clone())
             trace["spec"].append(all_spec.clone())
             trace["pred"].append(all_llm_pred.clone())
-            r = orig(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache, v_cache, cache_len_add)
+            r = orig(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, max_acc, k_cache, v_cache, cache_len_add, out_acc_ids)
             trace["acc"].append(r[0].clone())
             trace["n"].append(r[1].clone())
             return r

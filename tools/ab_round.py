@@ -13,8 +13,14 @@ import bench  # noqa: E402
 
 
 def main():
-    modname, attr = sys.argv[1].rsplit(".", 1)
-    mod = importlib.import_module("longspec_amd." + modname)
+    # "graphs": HIP-graph replay of the rounds on/off; otherwise <module>.<FLAG> of longspec_amd (rounds issued eagerly:
+    # a captured graph would not see the flag change)
+    graphs_ab = sys.argv[1] == "graphs"
+    if not graphs_ab:
+        modname, attr = sys.argv[1].rsplit(".", 1)
+        mod = importlib.import_module("longspec_amd." + modname)
+    else:
+        attr = "graphs"
     blocks, per = 6, 15
     dev = torch.device("cuda", 0)
     cfg = bench.make_config("llama3-8b-262k")
@@ -29,13 +35,23 @@ def main():
     with torch.inference_mode():
         st = m.begin_tree_decode(first, lens, 16384, bench.TREE, max_gen, eos_id=-1)
         st.eos = None
+
+        def set_flag(flag):
+            if graphs_ab:
+                st.use_graphs = flag
+            else:
+                st.use_graphs = False
+                setattr(mod, attr, flag)
+
+        if graphs_ab:
+            m.prepare_tree_graphs(st)
         for flag in (True, False):
-            setattr(mod, attr, flag)
+            set_flag(flag)
             for _ in range(4):
                 m.tree_round(st)
         for b in range(blocks):
             for flag in (True, False):
-                setattr(mod, attr, flag)
+                set_flag(flag)
                 m.tree_round(st)
                 torch.cuda.synchronize()
                 t0 = time.time()

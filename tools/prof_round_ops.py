@@ -30,6 +30,7 @@ def main():
     with torch.inference_mode():
         st = m.begin_tree_decode(first, lens, args.prefix, bench.TREE, max_gen, eos_id=-1)
         st.eos = None
+        st.use_graphs = False          # profile the launch-by-launch path
         for _ in range(3):
             m.tree_round(st)
         torch.cuda.synchronize()
