@@ -356,6 +356,7 @@ def main():
             out_v[:, 0] = first
             vs = m.begin_vanilla_decode(out_v, lens.clone(), lens.clone(), L_total)
             vs.use_graphs = vs.use_graphs and not args.no_graphs          # same treatment as the tree rounds
+            vs.step = m.GRAPH_AFTER - 2                                   # capture now, not after GRAPH_AFTER tokens
             for i in range(args.vanilla_steps + 4):                       # steps 1-2 eager, 3 captures, the rest replay
                 if i == 4:
                     torch.cuda.synchronize()

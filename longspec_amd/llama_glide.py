@@ -198,6 +198,9 @@ class LlamaGlide(LlamaForCausalLM):
         self.eval()
 
     GRAPH_ROUNDS = True      # capture tree rounds into HIP graphs (one per accepted-token count), see tree_round
+    GRAPH_AFTER = 256        # ... once a generation has run this many rounds: a capture costs ~10 ms and a replay saves
+                             # <= 0.1 ms on a fast host (more on a slow or busy one), so only long generations
+                             # (LongSpec's long-CoT case) pay it back; benchmarks capture up front (prepare_tree_graphs)
 
     # ------------------------------------------------------------------------------------------
     def set_max_gen_len(self, max_gen_len):
@@ -275,11 +278,11 @@ class LlamaGlide(LlamaForCausalLM):
         out[rows, (cl - il).long()] = llm_output.view(-1)
 
     def vanilla_step(self, vs):
-        """Decode one token.  On a GPU the step is captured into a HIP graph after two eager steps and replayed."""
+        """Decode one token.  On a GPU the step is captured into a HIP graph after GRAPH_AFTER eager steps and replayed."""
         vs.step += 1
         if vs.use_graphs:
             try:
-                if vs.graph is None and vs.step > 2:
+                if vs.graph is None and vs.step > self.GRAPH_AFTER:
                     self._set_hints(vs.P + vs.output_ids.size(1), vs.P + vs.output_ids.size(1))
                     cur = torch.cuda.current_stream()
                     vs.graph_stream = torch.cuda.Stream()
@@ -505,7 +508,7 @@ class LlamaGlide(LlamaForCausalLM):
         # HIP graphs of the round, one per `a`: on a GPU, without a KV shard (a collective inside a captured round is
         # not something this build could test) -- callers that bracket kernels with events switch it off per round
         st.use_graphs = bool(dev.type == "cuda" and self.model.layers[-1].self_attn.shard is None and self.GRAPH_ROUNDS)
-        st.graphs, st.graph_stream, st.graph_pool = {}, None, None
+        st.graphs, st.graph_stream, st.graph_pool, st.graphs_forced = {}, None, None, False
         st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
         st.tree_mask[:, :, 0] = 1
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
@@ -523,7 +526,7 @@ class LlamaGlide(LlamaForCausalLM):
         kernels the host cannot issue fast enough) become one."""
         a = st.a
         state = None
-        if st.use_graphs:
+        if st.use_graphs and (st.graphs_forced or st.num >= self.GRAPH_AFTER * st.bsz):
             state = self._graph_round(st, a)
         if state is None:
             # host bounds: no cache holds more than P + emitted (+ this round's speculative rows) valid rows
@@ -600,6 +603,7 @@ class LlamaGlide(LlamaForCausalLM):
         scribble on cache rows beyond the valid lengths."""
         if not st.use_graphs or st.graphs is False:
             return
+        st.graphs_forced = True
         names = ("cache_lens", "target_cache_lens_for_draft", "draft_cache_lens", "tree_mask", "all_spec", "history_logp_sum",
                  "acc_pad", "output_ids", "emitted_dev")
         try:

@@ -48,6 +48,25 @@ def test_generate_token_ids_match_reference(run):
     assert (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
 
 
+@pytest.mark.parametrize("run", [r for r in RUNS if r["name"] in ("mixed", "qwen_g7", "gqa_mixed", "mixed_small_tree")], ids=lambda r: r["name"])
+def test_graph_replayed_rounds_match_reference(run):
+    """The same golden runs with every round (and every vanilla step) replayed from a HIP graph as early as possible
+    (the default only starts capturing after GRAPH_AFTER rounds of a generation)."""
+    m = build(run)
+    m.GRAPH_AFTER = 0
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    kw = dict(max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
+    assert torch.equal(t_out.cpu(), run["tree_out"])
+    assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
+    v_out, v_num, _ = m.vanilla_generate(ids, pl, **kw)
+    assert torch.equal(v_out.cpu(), run["vanilla_out"])
+    # a second generation on the same model object starts from fresh graphs
+    t2, _, _, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
+    assert torch.equal(t2.cpu(), run["tree_out"])
+
+
 @pytest.mark.parametrize("run", list(cases.baseline_runs()), ids=lambda r: r["name"])
 def test_magicdec_baseline_matches_reference(run):
     m = build(run)
