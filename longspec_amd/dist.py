@@ -32,6 +32,7 @@ class KVShard:
         self._send = {}
         self._recv = {}
         self._pass_len = {}
+        self.prefill_ctx = None          # (first global row, local rows, prompt rows) while a sharded prefill runs
 
     # ---- lengths ---------------------------------------------------------------------------------
     def local_len(self, global_len: torch.Tensor) -> torch.Tensor:
@@ -64,6 +65,19 @@ class KVShard:
             self._send[key] = torch.empty(n_floats, dtype=torch.float32, device=device)
             self._recv[key] = torch.empty((self.world, n_floats), dtype=torch.float32, device=device)
         return self._send[key], self._recv[key]
+
+    def gather_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """All-gather of one equally-shaped tensor per rank along a new leading dimension (sharded prefill: every rank's
+        K or V rows of a layer)."""
+        rows = rows.contiguous()
+        out = rows.new_empty((self.world,) + tuple(rows.shape))
+        dist.all_gather_into_tensor(out.view(-1), rows.view(-1), group=self.group)
+        return out
+
+    def broadcast_from_tail(self, t: torch.Tensor) -> torch.Tensor:
+        dist.broadcast(t, src=self.world - 1 if self.group is None else dist.get_global_rank(self.group, self.world - 1),
+                       group=self.group)
+        return t
 
     def exchange(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
         dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)

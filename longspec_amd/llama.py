@@ -239,11 +239,37 @@ class LlamaAttention(nn.Module):
         return y, None
 
     def prefill(self, hidden_states, position_embeddings):          # llama.py:199-226
+        if self.shard is not None and self.shard.prefill_ctx is not None:
+            return self.sharded_prefill(hidden_states, position_embeddings)
         bsz, q_len, _ = hidden_states.size()
         q, k, v = self._qkv(hidden_states, position_embeddings)
         self.K_Cache = q.new_zeros((bsz, q_len + self.max_len, self.num_key_value_heads, self.head_dim))
         self.V_Cache = q.new_zeros((bsz, q_len + self.max_len, self.num_key_value_heads, self.head_dim))
         attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache)
+        return self.o_proj(attn.reshape(bsz, q_len, -1))
+
+    def sharded_prefill(self, hidden_states, position_embeddings):
+        """Prefill of this rank's slice of the prompt: ``hidden_states`` are the local rows
+        [lo, lo + n).  Every rank's K/V rows of the layer are all-gathered into a scratch cache laid out by global row, and
+        the local rows are appended onto rows [0, lo) of it with the SAME causal block-wise calls the single-GPU prefill
+        makes for those rows (same lengths, same grid bounds -- so the same numbers).  What stays is the local shard:
+        K_Cache/V_Cache = [local rows | room for the tail], exactly what ``dist.shard_model_kv`` leaves behind."""
+        sh = self.shard
+        lo, n, P = sh.prefill_ctx
+        bsz, q_len, _ = hidden_states.size()
+        assert q_len == n and 0 < n <= sh.Ls, "sharded prefill: every rank holds between 1 and shard_rows prompt rows"
+        q, k, v = self._qkv(hidden_states, position_embeddings)
+        Hkv, D = self.num_key_value_heads, self.head_dim
+        pad_k, pad_v = k.new_zeros((bsz, sh.Ls, Hkv, D)), v.new_zeros((bsz, sh.Ls, Hkv, D))
+        pad_k[:, :n], pad_v[:, :n] = k, v
+        # [W, bsz, Ls, Hkv, D] -> [bsz, W*Ls, Hkv, D]: global row = rank * Ls + i (every rank before the tail is full)
+        all_k = sh.gather_rows(pad_k).permute(1, 0, 2, 3, 4).reshape(bsz, sh.world * sh.Ls, Hkv, D)
+        all_v = sh.gather_rows(pad_v).permute(1, 0, 2, 3, 4).reshape(bsz, sh.world * sh.Ls, Hkv, D)
+        attn = self.ops.prefill_attention(q, k, v, all_k, all_v, start=lo)
+        rows = (n if sh.is_tail else sh.Ls) + self.max_len
+        self.K_Cache = q.new_zeros((bsz, rows, Hkv, D))
+        self.V_Cache = q.new_zeros((bsz, rows, Hkv, D))
+        self.K_Cache[:, :n], self.V_Cache[:, :n] = k, v
         return self.o_proj(attn.reshape(bsz, q_len, -1))
 
     STREAM_SINK, STREAM_WINDOW = 32, 1024      # StreamingLLM cache of the MagicDec baseline (llama.py:255-262)

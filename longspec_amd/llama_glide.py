@@ -97,6 +97,16 @@ class GlideAttention(nn.Module):
         attn = chunked_causal_prefill(self.ops, q, k, v, self.K_Cache, self.V_Cache, window_left=self.WINDOW)
         return self.o_proj(attn.reshape(bsz, q_len, self.hidden_size))
 
+    def prefill_cache_only(self, hidden_states, position_embeddings):
+        """What the draft's prefill leaves behind: the K/V rows of the prompt.  The layer's outputs are discarded by
+        every caller (:968-975), and these rows are a row-wise function of the token ids -- so the sequence-sharded path,
+        where no rank holds the whole target KV the cross-attention would read, fills the cache with just this."""
+        bsz, q_len, _ = hidden_states.size()
+        _, k, v = self._qkv(hidden_states, position_embeddings)
+        shape = (bsz, q_len + self.max_len + self.CACHE_PAD, self.num_key_value_heads, self.head_dim)
+        self.K_Cache, self.V_Cache = k.new_zeros(shape), v.new_zeros(shape)
+        self.K_Cache[:, :q_len], self.V_Cache[:, :q_len] = k, v
+
     def decoding(self, hidden_states, position_embeddings, cache_lens, K_Cache, V_Cache, llm_kv_len=None):   # :235-270
         bsz, q_len, _ = hidden_states.size()
         if K_Cache is None:
@@ -144,6 +154,9 @@ class LlamaGlideDecoderLayer(nn.Module):
 
     def set_max_gen_len(self, max_gen_len):
         self.self_attn.max_len = max_gen_len
+
+    def prefill_cache_only(self, hidden_states, position_embeddings):
+        self.self_attn.prefill_cache_only(self.input_layernorm(hidden_states), position_embeddings)
 
     def forward(self, hidden_states, position_embeddings, llm_kv, cache_lens=None, exec_type=None, llm_kv_len=None,
                 tree_mask=None, tree_mask_bits=None):
@@ -440,7 +453,10 @@ class LlamaGlide(LlamaForCausalLM):
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def tree_spec_generate(self, input_ids, prompt_length, tree_shape: Optional[List[int]] = None, max_gen_len=64,
-                           eos_id=151645, temperature=0.0):                                   # :915-1126
+                           eos_id=151645, temperature=0.0, shard=None):                       # :915-1126
+        """``shard`` (``dist.KVShard``, every rank of the group calls with the same arguments): the prompt is prefilled
+        and its KV kept sequence-sharded over the ranks (``_sharded_prefill``); decoding then runs replicated with one
+        exchange per attention call.  Returns the same values on every rank."""
         assert input_ids is not None, "please give the input"
         if temperature > 0:
             raise NotImplementedError("temperature > 0 (verify_stochastic) is a 'next' row (SURVEY 8(f).4)")
@@ -452,17 +468,23 @@ class LlamaGlide(LlamaForCausalLM):
         P = int(input_ids.size(1))
         input_len = prompt_length
         rows = torch.arange(bsz, device=dev)
-        # prefill LLM (:954-960)
-        self._set_hints(P, P)
-        hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
-        first = self.lm_head(hidden_states[rows, input_len - 1, ...]).argmax(dim=-1)
-        # prefill glide (:968-975)
         lens = input_len.to(device=dev, dtype=torch.int32).view(bsz)
         position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
-        hidden_states = self.model.embed_tokens(input_ids)
-        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-        self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
-                   cache_lens=lens.clone(), llm_kv_len=lens.clone(), exec_type="prefill")
+        for layer in self.model.layers:                    # a model object may be reused with and without a shard
+            layer.self_attn.shard = shard
+        self.glide.cross_attn.shard = shard
+        if shard is not None:
+            first = self._sharded_prefill(input_ids, input_len, position_ids, shard)
+        else:
+            # prefill LLM (:954-960)
+            self._set_hints(P, P)
+            hidden_states = self.model.forward(input_ids, exec_type="prefill").last_hidden_state
+            first = self.lm_head(hidden_states[rows, input_len - 1, ...]).argmax(dim=-1)
+            # prefill glide (:968-975)
+            hidden_states = self.model.embed_tokens(input_ids)
+            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
+                       cache_lens=lens.clone(), llm_kv_len=lens.clone(), exec_type="prefill")
         st = self.begin_tree_decode(first, lens, P, tree_shape, max_gen_len, eos_id)
         _sync(input_ids)
         start_time = time.time()
@@ -472,6 +494,36 @@ class LlamaGlide(LlamaForCausalLM):
         _sync(input_ids)
         elapsed_time = time.time() - start_time
         return st.output_ids, st.count, st.num, elapsed_time, st.spec_mask
+
+    def _sharded_prefill(self, input_ids, input_len, position_ids, shard):
+        """Sequence-sharded prefill: rank r runs the target model on prompt rows [r*Ls, (r+1)*Ls) only
+        (one all-gather of the layer's K/V rows per layer, ``LlamaAttention.sharded_prefill``) and keeps that slice of the
+        KV; the tail rank computes the first token and broadcasts it.  The draft layer's cache is filled on every rank
+        (its rows depend on the token ids only).  Work per rank: 1/W of the projections / MLP, between 1/W^2 (rank 0)
+        and (2W-1)/W^2 (tail) of the attention."""
+        bsz, P = input_ids.shape
+        assert bsz == 1 and int(input_len.view(-1)[0]) == P, "sharded prefill: batch 1, unpadded prompt"
+        lo = shard.start
+        hi = P if shard.is_tail else min(P, lo + shard.Ls)
+        assert hi > lo and (shard.world - 1) * shard.Ls < P <= shard.world * shard.Ls, \
+            "sharded prefill: shard_rows must be ceil(prompt / world)-like (every rank owns at least one row)"
+        for layer in self.model.layers:
+            layer.self_attn.shard = shard
+        self.glide.cross_attn.shard = shard
+        shard.prefill_ctx = (lo, hi - lo, P)
+        try:
+            self._set_hints(P, P)
+            hidden_states = self.model.forward(input_ids[:, lo:hi], position_ids=position_ids[:, lo:hi],
+                                               exec_type="prefill").last_hidden_state
+        finally:
+            shard.prefill_ctx = None
+        first = torch.zeros((bsz,), dtype=torch.int64, device=input_ids.device)
+        if shard.is_tail:
+            first = self.lm_head(hidden_states[:, hi - lo - 1, :]).argmax(dim=-1)
+        shard.broadcast_from_tail(first)
+        hidden_states = self.model.embed_tokens(input_ids)
+        self.glide.prefill_cache_only(hidden_states, self.model.rotary_emb(hidden_states, position_ids))
+        return first
 
     def begin_tree_decode(self, first_token, cache_lens, prompt_bound: int, tree_shape=None, max_gen_len=64, eos_id=151645):
         """State of the round loop right after the two prefills (``llama_glide.py:927-991``).

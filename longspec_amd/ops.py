@@ -443,19 +443,20 @@ def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, c
 PREFILL_CHUNK = 64
 
 
-def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1):
+def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: int = 0):
     """Prompt attention (K13) through the decode kernels: the prompt is appended to the (empty)
     caches ``PREFILL_CHUNK`` rows at a time with the causal(+window) append form of
     ``kvcache_attention`` -- the same function as ``flash_attn_func(causal=True[, window])``
     (``llama.py:218``, ``llama_glide.py:227``), evaluated block-wise.  [b,L,H,128] -> [b,L,H,128];
-    fills ``k_cache/v_cache[:, :L]``."""
+    fills ``k_cache/v_cache[:, start:start + L]``.  ``start`` > 0: the rows are positions [start, start + L) of a
+    prompt whose first ``start`` rows are already in the caches (sequence-sharded prefill)."""
     b, L, H, D = q.shape
     outs = []
     for s0 in range(0, L, PREFILL_CHUNK):
         s1 = min(L, s0 + PREFILL_CHUNK)
-        lens = torch.full((b,), s0, dtype=torch.int32, device=q.device)
+        lens = torch.full((b,), start + s0, dtype=torch.int32, device=q.device)
         outs.append(kvcache_attention(q[:, s0:s1], k_cache, v_cache, k[:, s0:s1], v[:, s0:s1], cache_seqlens=lens,
-                                      causal=True, window_size=(window_left, -1), kv_len_hint=s0))
+                                      causal=True, window_size=(window_left, -1), kv_len_hint=start + s0))
     return torch.cat(outs, dim=1)
 
 

@@ -132,11 +132,15 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, m
     return pad_ids, acc_num, dbl, pad_map
 
 
-def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1):
+def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1, start=0):
     L = q.shape[1]
-    k_cache[:, :L] = k
-    v_cache[:, :L] = v
-    return ref_ops.flash_attention(q, k, v, causal=True, window_size=(window_left, -1))
+    k_cache[:, start:start + L] = k
+    v_cache[:, start:start + L] = v
+    if start == 0:
+        return ref_ops.flash_attention(q, k, v, causal=True, window_size=(window_left, -1))
+    # rows [start, start+L) of a longer prompt: bottom-right aligned causal attention over the rows so far
+    lens = torch.full((q.shape[0],), start + L, dtype=torch.int32)
+    return ref_ops.kvcache_attention(q, k_cache, v_cache, cache_seqlens=lens, causal=True, window_size=(window_left, -1))
 
 
 class _ShardCall:

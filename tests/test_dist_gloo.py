@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, run_name, q):
+def _worker(rank, world, port, run_name, q, sharded_prefill=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -37,7 +37,19 @@ def _worker(rank, world, port, run_name, q):
     m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
     P = run["prompt_len"]
     ids, pl = run["prompt"], torch.tensor([P])
-    # replicated prefill (sequence-sharded prefill is a "next" row), then keep only the local slice
+    if sharded_prefill:
+        # the public entry point: sequence-sharded prefill + sharded decode
+        shard = KVShard(rank, world, shard_rows=(P + world - 1) // world)
+        out, count, num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"],
+                                                     eos_id=run["eos_id"], shard=shard)
+        # every rank holds only its slice of the prompt KV (+ room for the tail)
+        n_local = (P - shard.start) if shard.is_tail else shard.Ls
+        assert m.model.layers[0].self_attn.K_Cache.shape[1] == n_local + run["max_gen_len"] + 256
+        q.put((rank, out.clone(), int(count), int(num)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    # replicated prefill, then keep only the local slice
     glen = run["max_gen_len"]
     m.set_max_gen_len(glen + 256)
     m.glide.set_max_gen_len(glen + 256)
@@ -67,6 +79,23 @@ def test_sequence_sharded_tree_decode_matches_single_process(world, run_name):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, run_name, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for rank, out, count, num in res:
+        assert torch.equal(out, run["tree_out"]), f"rank {rank}: token ids differ from the single-process reference"
+        assert (count, num) == (run["tree_count"], run["tree_num"])
+
+
+@pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree")])
+def test_sequence_sharded_prefill_and_decode_match_single_process(world, run_name):
+    """``tree_spec_generate(..., shard=...)`` prefills rank-locally (one K/V all-gather per layer) and
+    decodes sharded; token ids and counters equal the single-process golden run on every rank."""
+    run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, run_name, q, True)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=600) for _ in range(world)]
     [p.join(timeout=60) for p in procs]

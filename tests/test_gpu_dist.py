@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, run_name, q):
+def _worker(rank, world, port, run_name, q, sharded_prefill=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -38,6 +38,15 @@ def _worker(rank, world, port, run_name, q):
     m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
     P, glen = run["prompt_len"], run["max_gen_len"]
     ids = run["prompt"].cuda()
+    if sharded_prefill:
+        shard = KVShard(rank, world, shard_rows=(P + world - 1) // world)
+        out, count, num, _, _ = m.tree_spec_generate(ids, torch.tensor([P], device="cuda"), tree_shape=run["tree_shape"],
+                                                     max_gen_len=glen, eos_id=run["eos_id"], shard=shard)
+        torch.cuda.synchronize()
+        q.put((rank, out.cpu(), int(count), int(num)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     with torch.inference_mode():
         m.set_max_gen_len(glen + 256)
         m.glide.set_max_gen_len(glen + 256)
@@ -69,6 +78,24 @@ def test_sharded_tree_decode_on_gpu_matches_golden(run_name):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, run_name, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for rank, out, count, num in res:
+        assert torch.equal(out, run["tree_out"]), f"rank {rank}: token ids differ from the single-process reference"
+        assert (count, num) == (run["tree_count"], run["tree_num"])
+
+
+@pytest.mark.parametrize("run_name", ["mixed", "gqa_mixed"])
+def test_sharded_prefill_and_decode_on_gpu_match_golden(run_name):
+    """``tree_spec_generate(..., shard=...)``: sequence-sharded prefill (K/V all-gather per layer, rank-local causal
+    blocks through the decode kernels) + sharded decode, two ranks on one GPU."""
+    world = 2
+    run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, run_name, q, True)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=300) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
