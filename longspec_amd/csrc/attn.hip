@@ -962,8 +962,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             } else {
                 // steady state: ONE basic block holds the QK^T MFMAs of block j+1 and the VALU work of block j, so that
                 // the scheduler can lay them out as asked below: an MFMA, then the VALU instructions its 16 cycles hide
-#pragma unroll 1
-                for (int j = 0; j + 1 < nblocks; ++j) {
+                auto steady_step = [&](int j, auto masked) {
                     step_head(j);
                     f32x4 s_next[2][QT];
                     qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
@@ -975,13 +974,18 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);         // 6 VALU
                     }
-                    mask_tail(s_next, j + 1);
+                    if constexpr (decltype(masked)::value) mask_tail(s_next, j + 1);
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) s_cur[kt][qt] = s_next[kt][qt];
                     step_tail(j);
-                }
+                };
+                // only the split's LAST block can cross the end of the cache: its masking (35 selects per lane when the
+                // compiler if-converts it into every iteration) is peeled off the loop
+#pragma unroll 1
+                for (int j = 0; j + 2 < nblocks; ++j) steady_step(j, std::false_type{});
+                if (nblocks > 1) steady_step(nblocks - 2, std::true_type{});
                 if (nblocks > 0) {                         // last block: nothing left to multiply
                     step_head(nblocks - 1);
                     softmax_store(nblocks - 1);
