@@ -347,6 +347,19 @@ def main():
                                      "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
                                      "launches_timed": pool.i,
                                      "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
+    if rank == 0:
+        # ---- the whole round against the HBM roofline: every weight streamed by the six passes (+ their
+        # small x / y) as counted on the bracketed rounds, the prefix K/V of the 32 verification calls and of the 5 draft
+        # cross-attention calls, the draft's 512-row window.  This rank's bytes over this rank's round time.
+        n_sampled = len(range(0, args.steps, SAMPLE))
+        gemm_b = gs["bytes"] / n_sampled
+        kv_row = 2 * Hkv * 128 * 2
+        attn_b = cfg.num_hidden_layers * ab + 5 * (Ls * kv_row) + 5 * (512 * kv_row)
+        round_b = gemm_b + attn_b
+        r_ach = round_b / (elapsed / args.steps) / 1e9
+        out["roofline_round"] = {"bound": "hbm", "achieved": round(r_ach, 2), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(r_ach / 8000.0, 4), "algorithmic_bytes_per_round": round(round_b),
+                                 "of_which_weights": round(gemm_b), "of_which_kv": round(attn_b)}
     if rank == 0 and world == 1 and not args.no_vanilla:
         # ---- speed-up denominator: vanilla autoregressive decode on the same model and prefix ----------
         with torch.inference_mode():
