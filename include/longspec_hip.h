@@ -147,6 +147,8 @@ typedef struct ls_linear_desc {
     int64_t ldx, ldy;
     const void* rope_cos; /* LS_EPI_QKV_ROPE: cos / sin [M, 128] dtype of the rows' positions (ls_rope_cos_sin) */
     const void* rope_sin;
+    const void* residual; /* LS_EPI_NONE, optional: [M, sum n[i]] dtype (row stride ldr) added to the ROUNDED projection, */
+    int64_t ldr;          /* `residual + mlp(x)` of the decoder layers (llama_glide.py:466); NULL = none                  */
 } ls_linear_desc;
 
 /* Weights are streamed in the MFMA A-operand layout: pack each nn.Linear.weight [N, K] (row-major,

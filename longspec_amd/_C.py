@@ -46,6 +46,7 @@ class LinearDesc(C.Structure):
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("n_splits", C.c_int32),
         ("ldx", C.c_int64), ("ldy", C.c_int64),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
     ]
 
 

@@ -59,6 +59,8 @@ struct GemmK {
     const char* rope_cos;        // EPI_QKV_ROPE: [M, 128] dtype tables of the rows' positions
     const char* rope_sin;
     int rope_segs;               // leading segments (q, k) that are rotated; the rest (v) are plain
+    const char* residual;        // EPI_NONE: [M, N] dtype added to the rounded output (`residual + mlp(x)`), or null
+    long ldr;
 };
 
 enum { EPI_NONE = 0, EPI_SILU_MUL = 1, EPI_QKV_ROPE = 2 };
@@ -369,7 +371,14 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
                 V4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = E::from_f32(r[h][0][mt][e] + bv[e]);
-                if (m < p.M && nn < n_lim) *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + nn) * 2) = o;
+                if (m < p.M && nn < n_lim) {
+                    if (p.residual != nullptr) {           // the projection is rounded first, then added (llama_glide.py:466)
+                        const V4 r4 = *reinterpret_cast<const V4*>(p.residual + ((long)m * p.ldr + nn) * 2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = E::from_f32(E::to_f32(o[e]) + E::to_f32(r4[e]));
+                    }
+                    *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + nn) * 2) = o;
+                }
             }
         }
     }
@@ -483,6 +492,8 @@ int make_plan(const ls_linear_desc* d, Plan& pl) {
         LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: epilogue");
     }
     if (d->ldy < pl.N) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: ldy < N");
+    if (d->residual && (d->epilogue != LS_EPI_NONE || d->ldr < pl.N || (d->ldr % 4) != 0))
+        LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: residual goes with LS_EPI_NONE, ldr >= N, ldr %% 4 == 0");
     const int groups = (rows + 63) / 64;
     // more than 32 token rows run ONE workgroup per CU (512 registers per wave): give it 128 weight rows when that
     // still fills the chip -- half the x staging traffic, half the workgroups (measured: lm_head 230 -> 209 us)
@@ -603,6 +614,8 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
     k.rope_cos = static_cast<const char*>(d->rope_cos);
     k.rope_sin = static_cast<const char*>(d->rope_sin);
     k.rope_segs = d->n_seg < 2 ? d->n_seg : 2;
+    k.residual = static_cast<const char*>(d->residual);
+    k.ldr = d->ldr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     if (d->dtype == LS_F16)

@@ -107,10 +107,12 @@ class DecodeLinear(nn.Linear):
     def streams(self, x) -> bool:
         return self.ops is not None and self.ops.linear_supported(x, self.in_features)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual``: returns ``residual + linear(x)`` (one launch when the input is decode-shaped)."""
         if self.streams(x):
-            return self.ops.linear(x, self.packed(), self.bias)
-        return F.linear(x, self.weight, self.bias)
+            return self.ops.linear(x, self.packed(), self.bias, residual=residual)
+        y = F.linear(x, self.weight, self.bias)
+        return y if residual is None else residual + y
 
 
 class DecodeEmbedding(nn.Embedding):
@@ -149,10 +151,11 @@ class LlamaMLP(nn.Module):
             self._gate_up_key = key
         return self._gate_up
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual``: returns ``residual + mlp(x)``, the add riding in down_proj's epilogue for decode-shaped inputs."""
         if self.gate_proj.bias is None and self.gate_proj.streams(x) and self.gate_proj.out_features % 16 == 0:
-            return self.down_proj(self.ops.mlp_gate_up(x, self._packed_gate_up()))
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+            return self.down_proj(self.ops.mlp_gate_up(x, self._packed_gate_up()), residual=residual)
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x), residual=residual)
 
 
 FUSE_QKV_ROPE = True      # decode-shaped q|k|v projections rotate q and k in the GEMM epilogue (tools/ab_round.py flips it)

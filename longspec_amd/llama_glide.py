@@ -176,9 +176,7 @@ class LlamaGlideDecoderLayer(nn.Module):
                                         cache_lens=cache_lens, exec_type="ca_" + exec_type, k_cache=llm_kv[0],
                                         v_cache=llm_kv[1], llm_kv_len=llm_kv_len, tree_mask=tree_mask, tree_mask_bits=bits)
         hidden_states, residual = self.post_cross_attention_layernorm(hidden_states, residual=residual)  # + residual, norm
-        hidden_states = self.mlp(hidden_states)
-        hidden_states = hidden_states + residual
-        return hidden_states
+        return self.mlp(hidden_states, residual=residual)           # `hidden_states = residual + mlp(...)` (:466)
 
 
 def _sync(t: torch.Tensor):

@@ -208,7 +208,7 @@ def set_linear_timing(hook):
     _linear_timing = hook
 
 
-def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None):
+def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None, residual=None):
     _dev(x)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -241,6 +241,12 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=Non
     d.epilogue = epilogue
     d.n_splits = n_splits
     d.ldx, d.ldy = x2.stride(0), n_out
+    if residual is not None:
+        _dev(residual)
+        r2 = residual.reshape(-1, residual.shape[-1])
+        if r2.shape != (M, n_out) or r2.dtype != x.dtype or r2.stride(-1) != 1 or r2.stride(0) % 4 != 0:
+            raise ValueError("linear: residual must be [..., N] of x's dtype with contiguous rows")
+        d.residual, d.ldr = r2.data_ptr(), r2.stride(0)
     if rope is not None:
         cos, sin = rope
         _dev(cos, sin)
@@ -267,9 +273,11 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=Non
     return y
 
 
-def linear(x: torch.Tensor, weight: PackedWeight, bias: Optional[torch.Tensor] = None, n_splits: int = 0, timing=None):
-    """``F.linear(x, weight, bias)`` for M <= 96 token rows: ``[..., K] -> [..., N]``."""
-    y = _linear_call(x, [weight], [bias], _C.LS_EPI_NONE, n_splits, timing)
+def linear(x: torch.Tensor, weight: PackedWeight, bias: Optional[torch.Tensor] = None, n_splits: int = 0, timing=None,
+           residual: Optional[torch.Tensor] = None):
+    """``F.linear(x, weight, bias)`` for M <= 80 token rows: ``[..., K] -> [..., N]``; with ``residual`` [..., N]:
+    ``residual + F.linear(...)`` (the projection rounded first, as the two separate operators do)."""
+    y = _linear_call(x, [weight], [bias], _C.LS_EPI_NONE, n_splits, timing, residual=residual)
     return y.view(*x.shape[:-1], weight.n)
 
 

@@ -65,7 +65,7 @@ def test_linear_desc_layout_matches_header():
             tail = tail.replace(kw, " ")
         fields += [f.strip() for f in tail.split(",") if f.strip()]
     assert fields == [f[0] for f in _C.LinearDesc._fields_]
-    assert ctypes.sizeof(_C.LinearDesc) == (1 + 3 + 3 + 1 + 2) * 8 + (2 + 3 + 4) * 4 + 4 + 2 * 8 + 2 * 8
+    assert ctypes.sizeof(_C.LinearDesc) == (1 + 3 + 3 + 1 + 2) * 8 + (2 + 3 + 4) * 4 + 4 + 2 * 8 + 2 * 8 + 2 * 8
 
 
 def test_ops_refuse_cpu_tensors():

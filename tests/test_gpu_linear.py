@@ -91,6 +91,24 @@ def test_qkv_in_one_launch(M):
         _check(o.cpu(), ref_ops.linear(x, w, b), _acc_tol(x, w))
 
 
+@pytest.mark.parametrize("N,K", [(4096, 14336), (4096, 4096), (1000, 256), (128256, 512)])
+@pytest.mark.parametrize("M", [1, 16, 33, 74])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_residual_epilogue(N, K, M, dtype):
+    """`residual + linear(x)` in the epilogue == the projection followed by torch's add, bit for bit."""
+    from longspec_amd import ops
+    x = _mk((1, M, K), 3, dtype=dtype).cuda()
+    w = ops.pack_weight(_mk((N, K), 4, K ** -0.5, dtype=dtype).cuda())
+    b = _mk((N,), 5, 0.3, dtype=dtype).cuda()
+    r = _mk((1, M, N), 6, dtype=dtype).cuda()
+    for bias in (None, b):
+        assert torch.equal(ops.linear(x, w, bias, residual=r), r + ops.linear(x, w, bias))
+    rs = _mk((1, M, N + 8), 7, dtype=dtype).cuda()[..., :N]            # strided residual rows
+    assert torch.equal(ops.linear(x, w, None, residual=rs), rs + ops.linear(x, w, None))
+    with pytest.raises(ValueError):
+        ops.linear(x, w, None, residual=r[..., :N - 4])
+
+
 @pytest.mark.parametrize("dims", [(4096, 1024, 4096), (512, 128, 256), (5120, 5120, 5120), (1024, 256, 896)],
                          ids=lambda d: "x".join(map(str, d)))
 @pytest.mark.parametrize("M", [1, 6, 16, 30, 74, 80])
