@@ -30,14 +30,16 @@ from ._C import LS_NEW_DRAFT, LS_NEW_FLASH, LS_NEW_NONE, LS_NEW_TARGET, AttnDesc
 _DT = {torch.float16: _C.LS_F16, torch.bfloat16: _C.LS_BF16}
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream
-_cur_device = torch._C._cuda_getDevice
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream() -> int:
-    """Raw hipStream_t of torch's current stream (the C accessors: torch.cuda.current_stream() costs ~8 us of
-    Python per call, twice per operator)."""
-    return _raw_stream(_cur_device())
+    """Raw hipStream_t of torch's current stream (the C accessors when this torch has them: the public
+    torch.cuda.current_stream() costs ~8 us of Python per call, twice per operator)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _dtype(t: torch.Tensor) -> int:
