@@ -269,6 +269,18 @@ int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int ma
                    int64_t* state, int64_t* tree_mask, int64_t* all_spec, float* logp_sum, int F,
                    int32_t* target_lens, int target_add, int32_t* draft_kv_lens, void* stream);
 
+/* End of a chain-speculation round (spec_generate, llama_glide.py:738-770), gamma draft tokens:
+ *   verification = cumprod(llm[:, :-1] == spec[:, 1:]); correct_len = sum + 1; llm[:, 1:] *= verification;
+ *   output_ids[z, base+1 .. base+gamma] = llm[z, :gamma]; output_ids[z, base+correct_len] = bonus = llm[z, correct_len-1]
+ *   (base = cache_lens - input_len); cache_lens += correct_len; draft_cache_lens = cache_lens - (correct_len == gamma+1);
+ *   next_spec_start_token [b,2] = (llm[correct_len-2], llm[correct_len-1]) when every draft was accepted, else [0] = bonus;
+ *   spec_buffer[z,0] = bonus; state [b,2] = (correct_len, any(output_ids[z, :base+correct_len+2] == eos)).
+ * llm_verify_output / spec_buffer [b, gamma+1] int64 (both updated in place), lengths int32. */
+int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int gamma, int64_t* output_ids,
+                    int64_t out_stride, int out_cap, int32_t* cache_lens, int32_t* draft_cache_lens,
+                    const int32_t* input_len, int64_t* next_spec_start_token, int has_eos, int64_t eos,
+                    int64_t* state, void* stream);
+
 /* `embed_tokens(ids)` of a short pass (llama.py:579, llama_glide.py:1003,1030): out [n,hidden] =
  * table[ids] (table [vocab,hidden] dtype, ids int64 inside the vocabulary). */
 int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int n,

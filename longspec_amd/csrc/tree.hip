@@ -254,6 +254,56 @@ __global__ __launch_bounds__(TT) void tree_commit_kernel(const int64_t* __restri
     }
 }
 
+// ---- end of a chain-speculation round (llama_glide.py:738-770) -------------------------------------------------------
+// verification = cumprod(llm[:, :-1] == spec[:, 1:]); correct_len = sum + 1; the verified ids and the bonus token go to
+// output_ids; cache_lens += correct_len; the next round's start tokens; state = (correct_len, eos hit).  One wave per row.
+__global__ __launch_bounds__(64) void chain_commit_kernel(int64_t* __restrict__ llm, int64_t* __restrict__ spec, int G,
+                                                          int64_t* __restrict__ output_ids, long out_stride, int out_cap,
+                                                          int32_t* cache_lens, int32_t* draft_cache_lens,
+                                                          const int32_t* __restrict__ input_len, int64_t* __restrict__ next_start,
+                                                          int has_eos, int64_t eos, int64_t* __restrict__ state) {
+    const int z = blockIdx.x, lane = threadIdx.x;
+    int64_t* l = llm + (long)z * (G + 1);
+    int64_t* sp = spec + (long)z * (G + 1);
+    int64_t* out = output_ids + (long)z * out_stride;
+    // lane i < G: does draft token i+1 match the target's prediction after token i?  correct = leading matches
+    const bool match = lane < G ? (l[lane] == sp[lane + 1]) : false;
+    const unsigned long long bal = __ballot(match);
+    const int lead = __ffsll((long long)~bal) - 1;                      // first lane that does not match (>= 0: lane G never does)
+    const int correct = lead + 1;                                       // 1 .. G+1
+    const long base = (long)cache_lens[z] - (long)input_len[z];
+    __syncthreads();
+    if (lane >= 1 && lane <= G && lane - 1 >= lead) l[lane] = 0;        // llm[:, 1:] *= verification
+    __syncthreads();
+    if (lane >= 1 && lane <= G && base + lane < out_cap) out[base + lane] = l[lane - 1];
+    const int64_t bonus = l[correct - 1];
+    __syncthreads();
+    if (lane == 0) {
+        if (base + correct < out_cap) out[base + correct] = bonus;
+        const int di = correct == G + 1 ? 1 : 0;
+        if (di) {
+            next_start[2 * z] = l[correct - 2];
+            next_start[2 * z + 1] = l[correct - 1];
+        } else {
+            next_start[2 * z] = bonus;
+        }
+        sp[0] = bonus;
+        const int cl = cache_lens[z] + correct;
+        cache_lens[z] = cl;
+        draft_cache_lens[z] = cl - di;
+        state[2 * z] = correct;
+    }
+    __syncthreads();
+    // EOS on output_ids[:, :emitted + 1] with emitted = base + 1 + correct (the host's counter after this round)
+    int hit = 0;
+    if (has_eos) {
+        const long n = min((long)out_cap, base + correct + 2);
+        for (long i = lane; i < n; i += 64) hit |= out[i] == eos;
+    }
+    const unsigned long long hb = __ballot(hit != 0);
+    if (lane == 0) state[2 * z + 1] = hb != 0ull ? 1 : 0;
+}
+
 // ---- token embedding of a short pass: out[i,:] = table[ids[i],:] ----------------------------------------------------
 __global__ __launch_bounds__(256) void embed_rows_kernel(const char* __restrict__ table, const int64_t* __restrict__ ids,
                                                          long vocab, int row_bytes, char* __restrict__ out) {
@@ -329,6 +379,20 @@ int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int ma
                        output_ids, (long)out_stride, out_cap, emitted, emitted_dev, has_eos, eos, state, tree_mask, all_spec,
                        logp_sum, F, target_lens, target_add, draft_kv_lens);
     LS_CHECK_LAUNCH("tree_commit_kernel");
+    return LS_OK;
+}
+
+int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int gamma, int64_t* output_ids,
+                    int64_t out_stride, int out_cap, int32_t* cache_lens, int32_t* draft_cache_lens, const int32_t* input_len,
+                    int64_t* next_spec_start_token, int has_eos, int64_t eos, int64_t* state, void* stream) {
+    if (!llm_verify_output || !spec_buffer || !output_ids || !cache_lens || !draft_cache_lens || !input_len ||
+        !next_spec_start_token || !state)
+        LS_FAIL(LS_ERR_INVALID_ARG, "chain_commit: null pointer");
+    if (b < 1 || gamma < 1 || gamma > 62 || out_cap < 1) LS_FAIL(LS_ERR_INVALID_ARG, "chain_commit: gamma=%d out_cap=%d", gamma, out_cap);
+    hipLaunchKernelGGL(chain_commit_kernel, dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream), llm_verify_output,
+                       spec_buffer, gamma, output_ids, (long)out_stride, out_cap, cache_lens, draft_cache_lens, input_len,
+                       next_spec_start_token, has_eos, eos, state);
+    LS_CHECK_LAUNCH("chain_commit_kernel");
     return LS_OK;
 }
 

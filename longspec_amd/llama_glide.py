@@ -373,7 +373,7 @@ class LlamaGlide(LlamaForCausalLM):
                        cache_lens=draft_cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
         stream_rows = self.model.layers[0].self_attn.STREAM_SINK + self.model.layers[0].self_attn.STREAM_WINDOW
         double_flag = False
-        double_input = None
+        input_len_i32 = input_len.to(device=dev, dtype=torch.int32).view(bsz).contiguous()
         next_spec_start_token = output_ids.new_zeros((bsz, 2))
         count = 0
         num = 0
@@ -409,40 +409,27 @@ class LlamaGlide(LlamaForCausalLM):
                                                llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
                                                llm_kv_len=cache_lens, exec_type="decoding")
                 if double_flag and spec_steps == 0:
-                    draft_cache_lens += 1 + double_input
+                    draft_cache_lens += 2                    # 1 + double_input (batch 1: the host knows the flag)
                     current_logp = self.lm_head(hidden_states[:, -2:, :])
-                    spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1)[rows, double_input.long()]
+                    spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp)[:, 1]
                 else:
                     draft_cache_lens += 1
                     current_logp = self.lm_head(hidden_states[:, -1, :])
-                    spec_buffer[:, spec_steps + 1] = current_logp.argmax(dim=-1).view(-1,)
+                    spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp).view(-1,)
             hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
             llm_verify_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -gamma - 1:, :]))
-            verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
-            correct_len = verification.sum(dim=-1) + 1
-            llm_verify_output[:, 1:] = llm_verify_output[:, 1:] * verification
-            col = (cache_lens - input_len).long().unsqueeze(1) + torch.arange(1, gamma + 1, device=dev)
-            output_ids[rows.unsqueeze(1), col] = llm_verify_output[:, :gamma]
-            bonus_token = llm_verify_output[rows, correct_len - 1]
-            output_ids[rows, (cache_lens - input_len).long() + correct_len] = bonus_token
-            cache_lens += correct_len.int()
-            double_input = correct_len.eq(gamma + 1).to(torch.int)
-            n_ok = int(correct_len[0])                       # the one host read of this round
+            # acceptance by cumulative match, verified ids + bonus token -> output_ids, cache_lens += correct_len, the next
+            # round's start tokens and draft_cache_lens = cache_lens - double_input (:738-770): one launch, one host read
+            state = self.ops.chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len_i32,
+                                          next_spec_start_token, eos).tolist()
+            n_ok, hit = state[0][0], any(row[1] for row in state)
             double_flag = n_ok == gamma + 1
-            if double_flag:
-                next_spec_start_token[:, 0] = llm_verify_output[rows, correct_len - 2]
-                next_spec_start_token[:, 1] = llm_verify_output[rows, correct_len - 1]
-                next_spec_start_token[:, 0] = (1 - double_input) * next_spec_start_token[:, 1] + double_input * next_spec_start_token[:, 0]
-            else:
-                next_spec_start_token[:, 0] = bonus_token
-            spec_buffer[:, 0] = bonus_token
             count += n_ok - 1
             num += bsz
             emitted += n_ok
-            draft_cache_lens = cache_lens - double_input
             if emitted - 1 + gamma + 2 > output_ids.size(1):
                 break
-            if eos is not None and bool((output_ids[:, :emitted + 1].eq(eos)).any()):
+            if hit:
                 break
         _sync(input_ids)
         elapsed_time = time.time() - start_time

@@ -800,6 +800,30 @@ def tree_commit(acc_ids, acc_num, output_ids, emitted: int, eos: Optional[int], 
     return state
 
 
+def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token,
+                 eos: Optional[int]) -> torch.Tensor:
+    """End of a chain-speculation round (``llama_glide.py:738-770``) in one launch: acceptance by cumulative match, the
+    verified ids + bonus token into ``output_ids``, the length bookkeeping and the next round's start tokens, in place.
+    Returns state [b,2] int64 = (correct_len, EOS hit) -- the round's one host read."""
+    _dev(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token)
+    b, g1 = llm_verify_output.shape
+    for t, name in ((llm_verify_output, "llm_verify_output"), (spec_buffer, "spec_buffer"), (next_spec_start_token, "next_spec_start_token")):
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise TypeError(f"chain_commit: {name} must be a contiguous int64 tensor")
+    if tuple(spec_buffer.shape) != (b, g1) or tuple(next_spec_start_token.shape) != (b, 2):
+        raise ValueError("chain_commit: spec_buffer [b, gamma+1], next_spec_start_token [b, 2]")
+    if output_ids.dtype != torch.int64 or output_ids.stride(1) != 1:
+        raise TypeError("chain_commit: output_ids must be int64 with contiguous rows")
+    state = torch.empty((b, 2), dtype=torch.int64, device=output_ids.device)
+    lib = _C.load()
+    _C.check(lib.ls_chain_commit(llm_verify_output.data_ptr(), spec_buffer.data_ptr(), b, g1 - 1, output_ids.data_ptr(),
+                                 output_ids.stride(0), output_ids.shape[1], _len_i32(cache_lens, b, "cache_lens"),
+                                 _len_i32(draft_cache_lens, b, "draft_cache_lens"), _len_i32(input_len, b, "input_len"),
+                                 next_spec_start_token.data_ptr(), 0 if eos is None else 1, 0 if eos is None else int(eos),
+                                 state.data_ptr(), _stream()), "ls_chain_commit")
+    return state
+
+
 EMBED_MAX_ROWS = 128
 
 

@@ -110,6 +110,36 @@ def tree_commit(acc_ids, acc_num, output_ids, emitted, eos, tree_mask, all_spec,
     return torch.stack([acc_num, hit], dim=1)
 
 
+def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token, eos):
+    """llama_glide.py:738-770 with the reference's tensor ops (batch 1, as the reference)."""
+    bsz, g1 = llm_verify_output.shape
+    gamma = g1 - 1
+    rows = torch.arange(bsz)
+    verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
+    correct_len = verification.sum(dim=-1) + 1
+    llm_verify_output[:, 1:] = llm_verify_output[:, 1:] * verification
+    col = (cache_lens - input_len).long().unsqueeze(1) + torch.arange(1, gamma + 1)
+    output_ids[rows.unsqueeze(1), col] = llm_verify_output[:, :gamma]
+    bonus_token = llm_verify_output[rows, correct_len - 1]
+    output_ids[rows, (cache_lens - input_len).long() + correct_len] = bonus_token
+    base = (cache_lens - input_len).long()
+    cache_lens += correct_len.int()
+    double_input = correct_len.eq(gamma + 1).to(torch.int)
+    for z in range(bsz):
+        if int(double_input[z]):
+            next_spec_start_token[z, 0] = llm_verify_output[z, correct_len[z] - 2]
+            next_spec_start_token[z, 1] = llm_verify_output[z, correct_len[z] - 1]
+        else:
+            next_spec_start_token[z, 0] = bonus_token[z]
+    spec_buffer[:, 0] = bonus_token
+    draft_cache_lens.copy_(cache_lens - double_input)
+    hit = torch.zeros_like(correct_len)
+    if eos is not None:
+        for z in range(bsz):
+            hit[z] = int(output_ids[z, :int(base[z]) + int(correct_len[z]) + 2].eq(eos).any())
+    return torch.stack([correct_len, hit], dim=1)
+
+
 def embed_supported(ids, weight):
     return False
 

@@ -162,3 +162,32 @@ def test_embed_rows(ops, dtype, shape):
     assert got.shape == (*shape, 4096)
     assert torch.equal(got.cpu(), torch.nn.functional.embedding(ids, w))
     assert ops.embed_supported(g(ids), g(w)) and not ops.embed_supported(g(torch.zeros(1, 200, dtype=torch.long)), g(w))
+
+
+@pytest.mark.parametrize("b,gamma,eos", [(1, 4, 7), (1, 4, None), (3, 4, 5), (2, 7, 3), (1, 1, 2)])
+def test_chain_commit(ops, b, gamma, eos):
+    """End of a chain-speculation round (llama_glide.py:738-770) against the reference's tensor ops."""
+    rng = np.random.RandomState(b * 10 + gamma)
+    for trial in range(12):
+        spec = torch.from_numpy(rng.randint(1, 9, size=(b, gamma + 1))).long()
+        llm = torch.from_numpy(rng.randint(1, 9, size=(b, gamma + 1))).long()
+        n_match = rng.randint(0, gamma + 1, size=b)                     # force every acceptance length to occur
+        for z in range(b):
+            llm[z, :n_match[z]] = spec[z, 1:1 + n_match[z]]
+        input_len = torch.from_numpy(rng.randint(5, 50, size=(b,))).int()
+        gen = torch.from_numpy(rng.randint(0, 30, size=(b,))).int()
+        cache_lens = input_len + gen
+        cap = 30 + 2 * gamma + 4
+        out = torch.from_numpy(rng.randint(10, 20, size=(b, cap))).long()
+        if trial % 3 == 0 and eos is not None:
+            out[:, 0] = eos
+        nss = torch.from_numpy(rng.randint(1, 9, size=(b, 2))).long()
+        dcl = torch.zeros(b, dtype=torch.int32)
+        cpu = [t.clone() for t in (llm, spec, out, cache_lens, dcl, nss)]
+        dev = [g(t.clone()) for t in (llm, spec, out, cache_lens, dcl, nss)]
+        st_c = oracle_ops.chain_commit(cpu[0], cpu[1], cpu[2], cpu[3], cpu[4], input_len, cpu[5], eos)
+        st_d = ops.chain_commit(dev[0], dev[1], dev[2], dev[3], dev[4], g(input_len), dev[5], eos)
+        assert torch.equal(st_c, st_d.cpu()), f"trial {trial}"
+        for tc, td, name in zip(cpu, dev, ("llm_verify_output", "spec_buffer", "output_ids", "cache_lens", "draft_cache_lens",
+                                           "next_spec_start_token")):
+            assert torch.equal(tc, td.cpu()), f"{name} (trial {trial})"
