@@ -343,7 +343,7 @@ def main():
         achieved = ab / (mean_us * 1e-6) / 1e9
         out["roofline_attention"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                                      "frac": round(achieved / 8000.0, 4), "traffic": a_traffic,
-                                     "kernel": "attn_partial_kernel (verification attention, stage 1)",
+                                     "kernel": "attn_partial_ws_kernel (verification attention, stage 1)",
                                      "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
                                      "launches_timed": pool.i,
                                      "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}

@@ -11,4 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/rp_$c -- python $R/bench.py --steps 6 --warmup 2 --no-vanilla > $R/gpurun_out/rp_$c.log 2>&1
 done
 python $R/tools/pmc_traffic.py $(find $R/gpurun_out/rp_FETCH_SIZE -name "*.db" | head -1) $(find $R/gpurun_out/rp_WRITE_SIZE -name "*.db" | head -1) skinny_gemm_kernel $R/gpurun_out/rp_traffic_gemm.json
+python $R/tools/pmc_traffic.py $(find $R/gpurun_out/rp_FETCH_SIZE -name "*.db" | head -1) $(find $R/gpurun_out/rp_WRITE_SIZE -name "*.db" | head -1) attn_partial_ws_kernel $R/gpurun_out/rp_traffic_attn.json
 rm -rf $R/gpurun_out/rp_stats $R/gpurun_out/rp_FETCH_SIZE $R/gpurun_out/rp_WRITE_SIZE
