@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="diagnostic: gloo lets several ranks share ONE GPU (with --share-gpu) to exercise the N > 1 code path")
+    ap.add_argument("--share-gpu", action="store_true", help="diagnostic: every rank uses cuda:0")
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
                          "with one rank, to price its extra launches without a second GPU")
@@ -218,6 +221,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.shard_path:
@@ -226,6 +231,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        elif args.backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
