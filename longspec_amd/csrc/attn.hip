@@ -1100,38 +1100,13 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const Attn
             else new_block_path<E, 2, LS_NEW_FLASH>(pk, smem);
         }
     } else {
-        // Roles by PLACEMENT: the S and the O wave of a pair must sit on the same SIMD (that is the point: the O
-        // wave's MFMAs run under the S wave's VALU work), and which SIMD a wave lands on is the dispatcher's choice.
-        // Each wave reads its SIMD id and draws a rank on it; rank 0 -> S, rank 1 -> O, pair = SIMD.  Should a SIMD
-        // ever receive more than two of the 8 waves, the surplus waves take the slots left free elsewhere.
-        int* s_cnt = reinterpret_cast<int*>(smem + WS_RING_B);      // role scratch in the (still unused) P buffers
-        int* s_free = s_cnt + 4;
-        int& s_nfree = s_cnt[12];
-        const int tid = threadIdx.x;
-        if (tid < 4) s_cnt[tid] = 0;
-        if (tid == 0) s_nfree = 0;
-        __syncthreads();
-        const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3;     // HW_ID.SIMD_ID
-        int rank = 0;
-        if ((tid & 63) == 0) rank = atomicAdd(&s_cnt[simd], 1);
-        rank = __builtin_amdgcn_readfirstlane(rank);
-        __syncthreads();
-        if (tid == 0) {
-            int n = 0;
-            for (int sd = 0; sd < 4; ++sd)
-                for (int r = min(s_cnt[sd], 2); r < 2; ++r) s_free[n++] = sd * 2 + r;
-        }
-        __syncthreads();
-        int slot = simd * 2 + rank;
-        if (rank >= 2) {
-            int k = 0;
-            if ((tid & 63) == 0) k = atomicAdd(&s_nfree, 1);
-            slot = s_free[__builtin_amdgcn_readfirstlane(k)];
-        }
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        __syncthreads();                           // the scratch is free again before the first P is written
-        if ((slot & 1) == 0) prefix_path_ws<E, true>(p, smem, (int)blockIdx.x - p.has_new, slot >> 1);
-        else prefix_path_ws<E, false>(p, smem, (int)blockIdx.x - p.has_new, slot >> 1);
+        // Roles by wave index: S = waves 0-3, O = waves 4-7, pair = wave & 3.  The dispatcher places the 8 waves of a
+        // workgroup round-robin over the 4 SIMDs, so the S and the O wave of a pair share one (the O wave's MFMAs run under
+        // the S wave's VALU work).  Drawing the roles from the SIMD id actually read (HW_ID) costs three barriers and
+        // measured 1.8 us SLOWER per launch at 16k, 6 us at 128k.
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (w < 4) prefix_path_ws<E, true>(p, smem, (int)blockIdx.x - p.has_new, w);
+        else prefix_path_ws<E, false>(p, smem, (int)blockIdx.x - p.has_new, w - 4);
     }
 }
 
