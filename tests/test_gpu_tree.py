@@ -191,3 +191,41 @@ def test_chain_commit(ops, b, gamma, eos):
         for tc, td, name in zip(cpu, dev, ("llm_verify_output", "spec_buffer", "output_ids", "cache_lens", "draft_cache_lens",
                                            "next_spec_start_token")):
             assert torch.equal(tc, td.cpu()), f"{name} (trial {trial})"
+
+
+def test_largest_tree_all_operators(ops):
+    """928 nodes (the operators take up to 1024), 16 levels of up to 64 nodes: growth, verification inputs, collapse and
+    commit against the reference's tensor ops."""
+    shape = [7, 24] + [64] * 14
+    (tm, spec, logp), (tm_d, spec_d, logp_d), acc_n = grow_both(ops, shape, 1, 32000, seed=77)
+    Fn, gamma = acc_n[-1], len(shape)
+    assert Fn == 928
+    R = Fn - 1 + gamma + 1
+    rng = np.random.RandomState(5)
+    acc_pad = torch.from_numpy(rng.randint(1, 5000, size=(1, gamma + 1))).long()
+    lens = torch.tensor([12345], dtype=torch.int32)
+    a = 3
+    v_c, p_c, m_c = oracle_ops.tree_verify_inputs(acc_pad[:, :a], a, spec, tm, lens, R)
+    v_d, p_d, m_d = ops.tree_verify_inputs(g(acc_pad)[:, :a], a, spec_d, tm_d, g(lens), R)
+    assert torch.equal(v_c, v_d.cpu()) and torch.equal(p_c, p_d.cpu()) and torch.equal(pack_bits(m_c), m_d.cpu())
+    # the target agrees with the draft along one root-to-leaf path and nowhere else
+    pred = torch.full((1, Fn), 31999, dtype=torch.int64)
+    node = Fn - 1
+    while node != 0:
+        row = tm[0, node].clone()
+        row[node] = 0
+        father = int(row.nonzero().max())
+        pred[0, father] = spec[0, node]
+        node = father
+    ids_c, num_c, dbl_c, map_c = oracle_ops.tree_collapse(spec, pred, tm, lens, acc_n[-2], gamma + 1)
+    ids_d, num_d, dbl_d, map_d = ops.tree_collapse(spec_d, g(pred), tm_d, g(lens), acc_n[-2], gamma + 1)
+    assert int(num_c[0]) == gamma + 1                                  # the whole path is accepted
+    assert torch.equal(num_c, num_d.cpu()) and torch.equal(ids_c, ids_d.cpu()) and torch.equal(map_c, map_d.cpu())
+    assert int(dbl_c[0]) == int(dbl_d[0])
+    out_c = torch.zeros((1, 64), dtype=torch.int64)
+    out_d = g(out_c.clone())
+    tl = torch.tensor([100], dtype=torch.int32)
+    st_c = oracle_ops.tree_commit(ids_c, num_c, out_c, 5, 31999, tm, spec, logp, target_lens=tl.clone(), target_add=a)
+    st_d = ops.tree_commit(ids_d, num_d, out_d, 5, 31999, tm_d, spec_d, logp_d, target_lens=g(tl.clone()), target_add=a)
+    assert torch.equal(st_c, st_d.cpu()) and torch.equal(out_c, out_d.cpu())
+    assert torch.equal(tm, tm_d.cpu()) and torch.equal(spec, spec_d.cpu())
