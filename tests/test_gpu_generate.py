@@ -77,3 +77,19 @@ def test_magicdec_baseline_matches_reference(run):
     assert torch.equal(out.cpu(), run["magicdec_out"])
     vt, vnum, _ = m.vanilla_torch_generate(ids, pl, max_gen_len=run["max_gen_len"])
     assert torch.equal(vt.cpu(), run["vanilla_torch_out"]) and vnum == run["vanilla_torch_num"]
+
+
+@pytest.mark.parametrize("tree_shape", [[1], [4], [2, 2], [8, 8, 8], [3, 1, 5, 2], [4, 16, 16, 16, 16, 16]], ids=str)
+@pytest.mark.parametrize("gen", [5, 17, 48])
+def test_tree_shapes_and_lengths_are_lossless(tree_shape, gen):
+    """Any tree shape and any output budget: tree decoding emits exactly the vanilla continuation (the toy model's
+    logit margins exclude ties) and respects the budget."""
+    run = [r for r in RUNS if r["name"] == "mixed"][0]
+    m = build(run)
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    v_out, _, _ = m.vanilla_generate(ids, pl, max_gen_len=gen, eos_id=-1)
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=tree_shape, max_gen_len=gen, eos_id=-1)
+    n = int(t_count) + int(t_num)
+    assert 1 <= n <= gen and t_out.shape == (1, gen)
+    assert torch.equal(t_out[0, :n], v_out[0, :n])
