@@ -108,7 +108,10 @@ def rope_cases():
 
 
 def generate_runs(family="llama"):
-    g = load_golden("generate" if family == "llama" else "generate_qwen2")
+    """family: "llama", "qwen2", or "qwen2_bf16" (the Qwen2 twin in bfloat16, as inference_qwq.py runs QwQ)."""
+    dtype = torch.bfloat16 if family == "qwen2_bf16" else torch.float16
+    g = load_golden({"llama": "generate", "qwen2": "generate_qwen2", "qwen2_bf16": "generate_qwen2_bf16"}[family])
+    family = "llama" if family == "llama" else "qwen2"
     for name in [str(x) for x in g["runs"]]:
         over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
         cfg = toy.toy_config(**over)
@@ -119,7 +122,7 @@ def generate_runs(family="llama"):
             "RNG drift: regenerate goldens"
         d = dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]),
                  prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]),
-                 tree_shape=[int(x) for x in g[f"{name}_tree_shape"]], family=family,
+                 tree_shape=[int(x) for x in g[f"{name}_tree_shape"]], family=family, dtype=dtype,
                  eos_id=int(g[f"{name}_eos_id"]) if f"{name}_eos_id" in g else 151645)
         for k in ("vanilla_out", "tree_out", "chain_out", "tr_tree_mask", "tr_all_spec", "tr_llm_pred", "tr_acc_ids",
                   "tr_acc_num", "tr_cache_lens"):

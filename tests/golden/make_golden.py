@@ -398,7 +398,7 @@ def import_reference_qwen2():
     return qwen2, qwen2_glide
 
 
-def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd):
+def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd, dtype=torch.float16):
     from transformers import Qwen2Config
     hc = Qwen2Config(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                      num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
@@ -415,7 +415,7 @@ def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd):
             qwen2.Qwen2ForCausalLM.__init__(self, config)
             self.glide = qwen2_glide.Qwen2GlideDecoderLayer(config)
 
-    m = RefGlide(hc).half().eval()
+    m = RefGlide(hc).to(dtype).eval()
     for mod in m.modules():                   # keep inv_freq in fp32, as from_pretrained(torch_dtype=float16) does
         if isinstance(mod, qwen2.Qwen2RotaryEmbedding):
             inv, _ = mod.rope_init_fn(hc, None)
@@ -429,6 +429,9 @@ def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd):
 
 def gen_generate(llama, llama_glide, family="llama"):
     arrays = {}
+    bf16 = family == "qwen2_bf16"             # the QwQ configuration runs in bfloat16 (inference_qwq.py)
+    if bf16:
+        family = "qwen2"
     if family == "qwen2":
         qwen2, qwen2_glide = import_reference_qwen2()
     runs = [
@@ -447,11 +450,16 @@ def gen_generate(llama, llama_glide, family="llama"):
          170, 48, [4, 8, 8]),
         ("qwen_rand", {"attention_bias": 1}, 23, 1.0, 90, 32, [4, 16, 16, 16, 16]),
     ]
+    if bf16:
+        runs = [("qwen_bf16_g5", {"attention_bias": 1, "hidden_size": 640, "num_attention_heads": 5, "num_key_value_heads": 1}, 31,
+                 0.012, 150, 40, [4, 16, 16, 16, 16]),
+                ("qwen_bf16_g7", {"attention_bias": 1, "hidden_size": 896, "num_attention_heads": 7, "num_key_value_heads": 1}, 32,
+                 0.012, 120, 36, [4, 8, 8])]
     for name, over, wseed, agree, plen, glen, shape in runs:
         cfg = toy.toy_config(**over)
         tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
         if family == "qwen2":
-            m = build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt, drf)
+            m = build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt, drf, dtype=torch.bfloat16 if bf16 else torch.float16)
         else:
             m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
         install_triton_stubs()      # after model construction
@@ -510,7 +518,8 @@ def gen_generate(llama, llama_glide, family="llama"):
             f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
             f"{name}_tr_cache_lens": torch.cat(trace["cache_lens"], 0),
         })
-    save("generate" if family == "llama" else "generate_qwen2", runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
+    save("generate" if family == "llama" else ("generate_qwen2_bf16" if bf16 else "generate_qwen2"),
+         runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
 
 
 # --------------------------------------------------------------------------- #
@@ -606,6 +615,9 @@ def main():
     llama, llama_glide, triton_tree_attn, train_llama = import_reference()
     if "--only-baselines" in sys.argv:
         gen_baselines(llama, llama_glide)
+        return
+    if "--only-qwen2-bf16" in sys.argv:
+        gen_generate(llama, llama_glide, family="qwen2_bf16")
         return
     if "--only-qwen2" in sys.argv:            # add the Qwen2 fixture without touching the others
         gen_generate(llama, llama_glide, family="qwen2")

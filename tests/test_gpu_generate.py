@@ -7,12 +7,16 @@ import cases
 
 pytestmark = pytest.mark.gpu
 RUNS = list(cases.generate_runs()) + list(cases.generate_runs("qwen2"))
+# bfloat16 (how inference_qwq.py runs QwQ).  The reference's Triton tree kernel cannot be run in bf16 in the build
+# container (the interpreter computes in numpy, which has no bfloat16: its outputs are off by 1e9), so the reference's
+# bf16 TREE run is lossless but drafts garbage; its vanilla and chain runs (no Triton) are valid goldens.
+RUNS_BF16 = list(cases.generate_runs("qwen2_bf16"))
 
 
 def build(run):
     from longspec_amd.llama_glide import LlamaGlide
     from longspec_amd.qwen2_glide import Qwen2Glide
-    m = (Qwen2Glide if run["family"] == "qwen2" else LlamaGlide)(run["cfg"], device="cuda")          # default ops = the HIP operator layer
+    m = (Qwen2Glide if run["family"] == "qwen2" else LlamaGlide)(run["cfg"], device="cuda", dtype=run.get("dtype", torch.float16))   # default ops = the HIP operator layer
     m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
     return m
 
@@ -93,3 +97,20 @@ def test_tree_shapes_and_lengths_are_lossless(tree_shape, gen):
     n = int(t_count) + int(t_num)
     assert 1 <= n <= gen and t_out.shape == (1, gen)
     assert torch.equal(t_out[0, :n], v_out[0, :n])
+
+
+@pytest.mark.parametrize("run", RUNS_BF16, ids=lambda r: r["name"])
+def test_bf16_generate_matches_reference(run):
+    """bfloat16 end to end on the HIP kernels: vanilla and chain decoding against the reference's bf16 goldens (token ids and
+    counters), tree decoding against the vanilla continuation (see RUNS_BF16)."""
+    m = build(run)
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    kw = dict(max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    v_out, v_num, _ = m.vanilla_generate(ids, pl, **kw)
+    assert torch.equal(v_out.cpu(), run["vanilla_out"]) and v_num == run["vanilla_num"]
+    s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, **kw)
+    assert torch.equal(s_out.cpu(), run["chain_out"]) and (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
+    n = int(t_count) + int(t_num)
+    assert torch.equal(t_out[0, :n].cpu(), run["vanilla_out"][0, :n])
