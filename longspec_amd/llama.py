@@ -15,7 +15,6 @@ operators; the product default is the HIP operator layer, which raises on CPU te
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
 from typing import Optional
 

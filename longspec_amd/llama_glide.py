@@ -17,10 +17,9 @@ import time
 from typing import List, Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
-from .llama import (DecodeLinear, LlamaForCausalLM, LlamaMLP, LlamaRMSNorm, LlamaRotaryEmbedding, chunked_causal_prefill,
+from .llama import (DecodeLinear, LlamaForCausalLM, LlamaMLP, LlamaRMSNorm, chunked_causal_prefill,
                     project_qkv, _default_ops)
 
 

@@ -8,7 +8,6 @@ and equality on >= 99 % of the elements."""
 import pytest
 import torch
 
-import toy
 from oracle import ref_ops
 
 pytestmark = pytest.mark.gpu

@@ -6,7 +6,6 @@ import pytest
 import torch
 
 import oracle_ops
-from oracle import ref_ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
