@@ -182,8 +182,11 @@ def cpu_baseline(cfg, L, sample_calls, tau):
     vc = torch.randn(1, L + 80, Hkv, 128, generator=g).to(torch.float16)
     c_port.verify_attention(q, k, v, kc, vc, 64, tm, False)             # warm-up (loads the library)
     t0 = time.time()
-    for _ in range(sample_calls):
+    done = 0
+    while done < sample_calls and (done < 4 or time.time() - t0 < 12.0):     # bounded: ~10 s of host time, >= 4 calls
         c_port.verify_attention(q, k, v, kc, vc, L, tm, False)
+        done += 1
+    sample_calls = done
     per_call = (time.time() - t0) / sample_calls
     round_s = per_call * cfg.num_hidden_layers
     return {"value": round(tau / round_s, 4), "unit": "accepted tokens/s", "cores": os.cpu_count(), "kind": "port",
@@ -205,7 +208,7 @@ def main():
     ap.add_argument("--prefix-per-gpu", type=int, default=16384)
     ap.add_argument("--agreement", type=float, default=0.02)
     ap.add_argument("--vanilla-steps", type=int, default=16)
-    ap.add_argument("--cpu-sample-calls", type=int, default=8)
+    ap.add_argument("--cpu-sample-calls", type=int, default=64)     # ~10 s of host time at 16k
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
