@@ -7,11 +7,12 @@
 
 A *step* is one decode round of ``LlamaGlide.tree_spec_generate`` (tree_shape 4 16 16 16 16): five
 draft passes growing the 69-node beam tree, one 74-row target pass through all 32 layers with the
-hybrid tree-verification attention, accept/collapse.  Workload at N = 1: BASELINE.json configs[1]
-(Llama-3-8B-Instruct-262k dimensions + longspec draft layer, 16k-token synthetic prefix, fp16,
-temperature 0).  For N > 1 every GPU keeps a 16k-row shard of the prefix (weak scaling: N = 8 is the
-128k-context configs[2]); the prefix KV is sequence-sharded, partial attention outputs are merged
-with one RCCL all-gather per attention call (longspec_amd/dist.py).
+hybrid tree-verification attention, accept/collapse.  Default workload = the configuration BASELINE.json's
+metric is quoted on: Llama-3-8B-Instruct-262k dimensions + longspec draft layer, **131072-token** synthetic
+prefix, fp16, temperature 0 -- it fits one GPU (16 GiB of KV).  ``--gpus N`` splits that FIXED prefix N ways
+by sequence (strong scaling; 16k rows per GPU at N = 8 = configs[2]); partial attention outputs are merged
+with one RCCL all-gather per attention call (longspec_amd/dist.py).  ``--prefix-per-gpu R`` is the secondary
+weak-scaling mode (R rows on every GPU; ``--prefix-per-gpu 16384`` at N = 1 is configs[1]).
 
 Synthetic data: random-init weights of the named architecture made "mixed-agreement" (o_proj and
 down_proj scaled by --agreement) so that the shared-embedding draft is accepted
@@ -196,6 +197,81 @@ def cpu_baseline(cfg, L, sample_calls, tau):
                       f"measured tau"}
 
 
+def cpu_baseline_round(tree, layers_sample=4, prefix=4096, rounds=2):
+    """The FULL decode round on the host cores at BASELINE.json configs[0] scale (Vicuna-7B-v1.5-16k dimensions,
+    4k-token synthetic prefix, tree_shape 4 16 16 16 16, fp16 storage): this repository's host logic driven by the
+    oracle's CPU operators (tests/oracle_ops.py; verification attention through the OpenMP C restatement).  Bounded
+    sample: `layers_sample` of the 32 target layers are instantiated and timed (they are identical in shape), the
+    draft layer / lm_head / tree bookkeeping run in full; the round time is extrapolated as
+    non_layer_time + 32 / layers_sample * layer_time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ops
+    from oracle import c_port, ref_ops
+    from longspec_amd.llama_glide import LlamaGlide
+
+    class CpuOps:
+        def __getattr__(self, name):
+            return getattr(oracle_ops, name)
+
+        @staticmethod
+        def verify_attention(q, k_new, v_new, k_cache, v_cache, cache_lens, mask_bits, last_layer, softmax_scale=1 / (128 ** 0.5),
+                             kv_len_hint=None, n_splits=0):
+            return c_port.verify_attention(q.contiguous(), k_new.contiguous(), v_new.contiguous(), k_cache, v_cache,
+                                           int(cache_lens[0]), mask_bits, last_layer, softmax_scale)
+
+    cfg = make_config("vicuna-7b-16k")
+    full_layers = cfg.num_hidden_layers
+    cfg.num_hidden_layers = layers_sample
+    torch.manual_seed(7)
+    m = LlamaGlide(cfg, ops=CpuOps(), dtype=torch.float16)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("norm.weight"):
+                prm.fill_(1.0)
+            elif name.endswith(".bias"):
+                prm.zero_()
+            else:
+                prm.copy_(torch.randn(prm.shape, dtype=torch.float32).mul_(0.02 if "embed" not in name else 1.0))
+    max_gen = 6 * (rounds + 3) + 16
+    max_rows = max_gen + 256
+    m.set_max_gen_len(max_rows)
+    m.glide.set_max_gen_len(max_rows)
+    synth_kv(m, prefix, prefix, max_rows, "cpu", seed=99)
+    lens = torch.tensor([prefix], dtype=torch.int32)
+    first = torch.tensor([1000], dtype=torch.int64)
+    layer_s = [0.0]
+    for layer in m.model.layers:
+        fwd = layer.forward
+
+        def timed(*a, _f=fwd, **k):
+            t = time.time()
+            r = _f(*a, **k)
+            layer_s[0] += time.time() - t
+            return r
+        layer.forward = timed
+    with torch.inference_mode():
+        st = m.begin_tree_decode(first, lens, prefix, tree, max_gen, eos_id=-1)
+        st.eos = None
+        st.use_graphs = False
+        m.tree_round(st)                                   # warm-up (thread pools, allocator)
+        layer_s[0] = 0.0
+        tok0 = st.emitted
+        t0 = time.time()
+        for _ in range(rounds):
+            m.tree_round(st)
+        total = (time.time() - t0) / rounds
+        tokens = (st.emitted - tok0) / rounds
+    lay = layer_s[0] / rounds
+    full = (total - lay) + lay * full_layers / layers_sample
+    return {"value": round(tokens / full, 4), "unit": "accepted tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{rounds} full decode rounds (5 draft passes + 74-row verify pass + tree bookkeeping) of vicuna-7b-16k dims, "
+                      f"{prefix}-token synthetic prefix, host logic of this repository on the oracle's CPU operators (torch-CPU fp16 "
+                      f"linears, oracle/ref_ops.py, oracle/oracle_c.c OpenMP verification attention); {layers_sample} of "
+                      f"{full_layers} target layers instantiated: measured {total * 1e3:.0f} ms/round of which {lay * 1e3:.0f} ms in "
+                      f"the {layers_sample} layers -> {full * 1e3:.0f} ms/round extrapolated to {full_layers} layers; tau {tokens:.2f} "
+                      f"of this random-weight model"}
+
+
 SAMPLE = 10      # every SAMPLE-th timed round is issued launch by launch with HIP events around the roofline kernels
 
 
@@ -205,10 +281,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="llama3-8b-262k", choices=sorted(MODELS))
-    ap.add_argument("--prefix-per-gpu", type=int, default=16384)
+    ap.add_argument("--prefix-total", type=int, default=131072,
+                    help="prefix tokens of the whole job, split by sequence over --gpus (strong scaling; the metric's config)")
+    ap.add_argument("--prefix-per-gpu", type=int, default=0,
+                    help="secondary mode: this many prefix rows on EVERY GPU (weak scaling; 16384 at N = 1 is configs[1])")
     ap.add_argument("--agreement", type=float, default=0.02)
     ap.add_argument("--vanilla-steps", type=int, default=16)
-    ap.add_argument("--cpu-sample-calls", type=int, default=64)     # ~10 s of host time at 16k
+    ap.add_argument("--cpu-sample-calls", type=int, default=64)     # bounded by time below: ~12 s of host time
+    ap.add_argument("--no-cpu-round", action="store_true", help="skip the full-round CPU baseline at configs[0] scale")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
@@ -241,7 +321,12 @@ def main():
 
     cfg = make_config(args.model)
     H, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
-    Ls = args.prefix_per_gpu
+    weak = args.prefix_per_gpu > 0
+    if weak:
+        Ls = args.prefix_per_gpu
+    else:
+        assert args.prefix_total % world == 0, "--prefix-total must divide by --gpus"
+        Ls = args.prefix_total // world
     L_total = Ls * world
     rounds = args.steps + args.warmup
     max_gen = 6 * (rounds + 2) + 16
@@ -309,10 +394,12 @@ def main():
     out = {
         "metric": "accepted tokens/sec (tree speculative decode, temperature 0)", "value": round(value, 3),
         "unit": "accepted tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
         "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix "
-                               f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1",
+                               f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1"
+                               + ("" if weak or args.model != "llama3-8b-262k" or L_total != 131072 else
+                                  " [BASELINE.json metric config: Llama-3-8B @128k ctx]"),
                    "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
                    "parallelism": "1 GPU" if world == 1 else f"prefix KV sequence-sharded x{world}, weights replicated"},
         "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
@@ -320,43 +407,35 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the weight-streaming GEMM (ls_linear_fwd), ~half of the round's GPU
-        # time.  Algorithmic bytes of a launch = packed weight + x + y; achieved = all bytes / all kernel time of the
-        # launches of the timed region, each bracketed by HIP events on the launch stream.
-        gs = gpool.stats()
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_gemm.json")
-        if os.path.exists(tf) and args.model == "llama3-8b-262k" and Ls == 16384:     # the PMC pass was taken on this workload
-            try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        g_ach = gs["bytes"] / (gs["us"] * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(g_ach, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(g_ach / 8000.0, 4), "traffic": traffic,
-                           "kernel": "skinny_gemm_kernel (ls_linear_fwd: q|k|v, o_proj, gate|up+SiLU, down_proj, lm_head of the "
-                                     "verify pass and the 5 draft passes)",
-                           "algorithmic_bytes_per_launch": round(gs["bytes"] / gs["launches"]),
-                           "avg_launch_us": round(gs["us"] / gs["launches"], 2), "launches_timed": gs["launches"],
-                           "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, SAMPLE)) / 1e3, 3),
-                           "launches_over_100MB_gbps": round(gs["big_gbps"], 1) if gs["big_gbps"] else None}
-        # ---- second kernel: hybrid verification attention, stage 1 (this rank's KV shard) ---------------------------
+        # ---- roofline of the kernel north_star names: the hybrid verification attention, stage 1 (this rank's KV shard).
+        # achieved = SURVEY 8(d)'s algorithmic bytes of one call / the kernel's average duration, every launch of the timed
+        # region's bracketed rounds measured with HIP events recorded by the C ABI on the launch stream.  `traffic` (PMC
+        # HBM bytes) cannot be observed inside this process: it is null here; the rocprofv3 --pmc passes of this same
+        # command are committed under profiles/ (tools/round_profile.sh) and quoted in DESIGN.md.
+        from longspec_amd import ops as _ops2
         mean_us = pool.mean_us()
         ab = algo_bytes_verify(Ls, H, Hkv)
-        a_traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tf) and args.model == "llama3-8b-262k" and Ls == 16384:
-            try:
-                a_traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                a_traffic = None
         achieved = ab / (mean_us * 1e-6) / 1e9
-        out["roofline_attention"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                                     "frac": round(achieved / 8000.0, 4), "traffic": a_traffic,
-                                     "kernel": "attn_partial_ws_kernel (verification attention, stage 1)",
-                                     "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2),
-                                     "launches_timed": pool.i,
-                                     "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1)}
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(achieved / 8000.0, 4), "traffic": None,
+                           "kernel": f"{_ops2.attn_kernel_name(H // Hkv * 74)} (hybrid tree-verification attention, stage 1: "
+                                     f"prefix flash-decoding + tree part)",
+                           "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2), "launches_timed": pool.i,
+                           "mfma_tflops": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12, 1),
+                           "mfma_frac_of_2500": round(4 * 74 * H * 128 * Ls / (mean_us * 1e-6) / 1e12 / 2500.0, 4)}
+        # ---- second kernel: the weight-streaming GEMM (ls_linear_fwd), the larger share of the round at short prefixes.
+        # Algorithmic bytes of a launch = packed weight + x + y.
+        gs = gpool.stats()
+        g_ach = gs["bytes"] / (gs["us"] * 1e-6) / 1e9
+        out["roofline_gemm"] = {"bound": "hbm", "achieved": round(g_ach, 2), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(g_ach / 8000.0, 4), "traffic": None,
+                                "kernel": "skinny_gemm_kernel (ls_linear_fwd: q|k|v, o_proj, gate|up+SiLU, down_proj, lm_head of the "
+                                          "verify pass and the 5 draft passes)",
+                                "algorithmic_bytes_per_launch": round(gs["bytes"] / gs["launches"]),
+                                "avg_launch_us": round(gs["us"] / gs["launches"], 2), "launches_timed": gs["launches"],
+                                "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, SAMPLE)) / 1e3, 3),
+                                "launches_over_100MB_gbps": round(gs["big_gbps"], 1) if gs["big_gbps"] else None}
+        out["attention_ms_per_round"] = round(mean_us * cfg.num_hidden_layers / 1e3, 3)
     if rank == 0:
         # ---- the whole round against the HBM roofline: every weight streamed by the six passes (+ their
         # small x / y) as counted on the bracketed rounds, the prefix K/V of the 32 verification calls and of the 5 draft
@@ -391,6 +470,8 @@ def main():
         out["speedup_vs_vanilla"] = round(value / vanilla_tps, 3)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, Ls, args.cpu_sample_calls, tau)
+            if not args.no_cpu_round:
+                out["cpu_baseline_round"] = cpu_baseline_round(TREE)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or args.shard_path:

@@ -89,6 +89,10 @@ size_t ls_attn_workspace_bytes(const ls_attn_desc* d);
 /* Number of prefix partials stage 1 writes for this descriptor (splits x key-slices). */
 int ls_attn_num_parts(const ls_attn_desc* d);
 
+/* Name of the stage-1 kernel that serves this descriptor ("attn_verify_kernel", "attn_partial_ws_kernel",
+ * "attn_partial_kernel"): what a profiler will show for the call -- diagnostics / benchmark labels only. */
+const char* ls_attn_kernel_name(const ls_attn_desc* d);
+
 /* One fused attention call = stage 1 (split-KV partials + new-block part) then
  * stage 2 (log-sum-exp combine + reference-order merge), both on `stream`.
  *  LS_NEW_NONE / LS_NEW_FLASH : flash_attn_with_kvcache as called at

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "liblongspec_hip.so")
+# LONGSPEC_HIP_LIB: diagnostic builds of the same library (tools/v2_stamps.py); the product path is the in-tree default
+LIB_PATH = os.environ.get("LONGSPEC_HIP_LIB") or os.path.join(HERE, "_lib", "liblongspec_hip.so")
 
 LS_F16, LS_BF16 = 0, 1
 LS_NEW_NONE, LS_NEW_FLASH, LS_NEW_TARGET, LS_NEW_DRAFT = 0, 1, 2, 3
@@ -59,6 +60,7 @@ SYMBOLS = {
     "ls_last_error": (C.c_char_p, []),
     "ls_attn_workspace_bytes": (C.c_size_t, [C.POINTER(AttnDesc)]),
     "ls_attn_num_parts": (C.c_int, [C.POINTER(AttnDesc)]),
+    "ls_attn_kernel_name": (C.c_char_p, [C.POINTER(AttnDesc)]),
     "ls_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_partial": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_reduce_local": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P, _P]),

@@ -28,6 +28,7 @@ DRAFT_TENSORS = (
 
 
 def load_config(path: str) -> SimpleNamespace:
+    path = resolve_path(path)
     with open(os.path.join(path, "config.json")) as f:
         d = json.load(f)
     d.setdefault("head_dim", d["hidden_size"] // d["num_attention_heads"])
@@ -39,16 +40,58 @@ def load_config(path: str) -> SimpleNamespace:
     return SimpleNamespace(**d)
 
 
-def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
-    """All tensors of a checkpoint directory (or single file)."""
-    files = []
+def resolve_path(path_or_id: str) -> str:
+    """A local checkpoint directory / file as is; anything else is taken as a Hugging Face hub id
+    (``lmsys/vicuna-7b-v1.5-16k``, ``sail/longspec-vicuna-7b-v1.5-16k`` ... -- what
+    ``inference_long-bench.py:41-62`` passes to ``from_pretrained``) and resolved through the local HF cache first,
+    then -- if the machine has network access -- downloaded with ``snapshot_download``."""
+    if os.path.exists(path_or_id):
+        return path_or_id
+    try:
+        from huggingface_hub import snapshot_download
+    except ImportError as e:                     # pragma: no cover
+        raise FileNotFoundError(f"{path_or_id!r} is not a local path and huggingface_hub is not installed") from e
+    patterns = ["*.json", "*.safetensors", "*.bin", "*.pth", "*.pt", "*.model"]
+    try:
+        return snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns)
+    except Exception:
+        pass
+    try:
+        return snapshot_download(path_or_id, allow_patterns=patterns)
+    except Exception as e:
+        raise FileNotFoundError(
+            f"{path_or_id!r} is neither a local checkpoint path nor a hub repository reachable from this machine "
+            f"(not in the HF cache, download failed: {type(e).__name__}).  Download it once "
+            f"(`huggingface-cli download {path_or_id}`) or pass a local directory.") from e
+
+
+def checkpoint_files(path: str):
+    """Tensor files of a checkpoint directory, the way ``from_pretrained`` picks them: a shard index
+    (``model.safetensors.index.json`` / ``pytorch_model.bin.index.json``) names the shard files; without one,
+    ``*.safetensors`` is preferred over ``pytorch_model*.bin`` over raw ``*.pth`` / ``*.pt`` state dicts."""
     if os.path.isfile(path):
-        files = [path]
-    else:
-        for pat in ("*.safetensors", "pytorch_model*.bin", "*.pth", "*.pt"):
-            files = sorted(glob.glob(os.path.join(path, pat)))
-            if files:
-                break
+        return [path]
+    for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json"):
+        ip = os.path.join(path, index)
+        if os.path.exists(ip):
+            with open(ip) as f:
+                names = sorted(set(json.load(f)["weight_map"].values()))
+            files = [os.path.join(path, n) for n in names]
+            absent = [f for f in files if not os.path.exists(f)]
+            if absent:
+                raise FileNotFoundError(f"{ip} names shard files that are missing: {absent[:3]}")
+            return files
+    for pat in ("*.safetensors", "pytorch_model*.bin", "*.pth", "*.pt"):
+        files = sorted(glob.glob(os.path.join(path, pat)))
+        if files:
+            return files
+    return []
+
+
+def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """All tensors of a checkpoint directory, single file or hub id."""
+    path = resolve_path(path)
+    files = checkpoint_files(path)
     if not files:
         raise FileNotFoundError(f"no checkpoint tensors under {path}")
     sd: Dict[str, torch.Tensor] = {}

@@ -260,7 +260,11 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
                         for (int e = 0; e < 4; ++e) st_coherent(mine + (mt * 4 + e) * 64 + lane, r[h][q][mt][e]);
                 }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the write-through stores are done
+        // Every thread drains its OWN write-through (sc1) partial stores before the barrier: only then may thread 0
+        // bump the slab counter.  (A workgroup-scope fence does not emit the wait -- the compiler left vmcnt(63)
+        // in front of the barrier -- so the last arriver, possibly on another XCD, could sum partials still in
+        // flight.  The asm wait is invisible to the waitcnt-elision pass: MI355X_MICROARCH, "Compiler hazard".)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         volatile unsigned& s_last = *reinterpret_cast<volatile unsigned*>(smem + p.flag_off);
         if (tid == 0) {

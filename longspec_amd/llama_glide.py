@@ -185,9 +185,14 @@ def _sync(t: torch.Tensor):
 
 class LlamaGlide(LlamaForCausalLM):
     """``LlamaGlide`` (``llama_glide.py:471-1245``).  ``LlamaGlide(config, target_model_path,
-    glide_path=None)`` loads a HF target directory and the draft checkpoint directory
-    (safetensors / .bin) when paths are given; ``target_model_path=None`` builds random-init
-    modules (tests, synthetic benchmarks)."""
+    glide_path=None)`` -- the reference's signature -- loads the target and the draft checkpoint (local
+    directories or hub ids, safetensors / .bin, sharded or not) in fp16 onto the current GPU, as the
+    reference's ``from_pretrained(..., torch_dtype=torch.float16, device_map="auto")`` does (``:474,480``);
+    ``config`` may be a ``transformers`` config object or any attribute namespace.
+    ``target_model_path=None`` builds random-init modules (tests, synthetic benchmarks).  ``device`` /
+    ``dtype`` / ``ops`` are extensions: with the default HIP operator layer the model lives on
+    ``torch.cuda.current_device()``; an injected ``ops`` (the CPU oracle of the host-logic tests) keeps
+    it where it is."""
 
     GLIDE_LAYER_CLS = LlamaGlideDecoderLayer
 
@@ -201,6 +206,8 @@ class LlamaGlide(LlamaForCausalLM):
             if glide_path is not None:
                 load_draft_checkpoint(self.glide, glide_path)
         self.to(dtype)
+        if device is None and ops is None and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())
         if device is not None:
             self.to(device)
         for p in self.parameters():

@@ -420,6 +420,20 @@ def _run(d: AttnDesc, device):
     _C.check(lib.ls_attn_fwd(C.byref(d), ws.data_ptr(), ws.numel(), _stream()), "ls_attn_fwd")
 
 
+def attn_kernel_name(M: int, verify: bool = True) -> str:
+    """Name of the stage-1 kernel a verification call with ``M = (H / Hkv) * sq`` rows per kv head is served by
+    (benchmark labels; ``ls_attn_kernel_name``)."""
+    d = AttnDesc()
+    d.b, d.sq, d.H, d.Hkv, d.dtype = 1, M, 1, 1, LS_F16
+    d.window_left = -1
+    d.q = d.k_cache = d.v_cache = d.cache_seqlens = 1            # non-null placeholders: nothing is dereferenced
+    d.q_stride_s = d.q_stride_h = d.kc_stride_s = d.kc_stride_h = 128
+    if verify:
+        d.new_mode, d.n_new, d.mask_words, d.mask_bits, d.k_new, d.v_new = LS_NEW_TARGET, min(M, 74), 3, 1, 1, 1
+    name = _C.load().ls_attn_kernel_name(C.byref(d))
+    return name.decode() if name else "?"
+
+
 def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, causal=False, window_size=(-1, -1),
                       return_softmax_lse=False, softmax_scale=None, kv_len_hint: Optional[int] = None, n_splits=0):
     """``flash_attn_with_kvcache`` as the reference uses it.  New

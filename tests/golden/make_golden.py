@@ -463,6 +463,12 @@ def gen_generate(llama, llama_glide, family="llama"):
         else:
             m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
         install_triton_stubs()      # after model construction
+        if bf16:
+            # The Triton interpreter computes in numpy (no bfloat16: its outputs are garbage in bf16), so the bf16 TREE runs
+            # take the reference's own pure-torch twin of that seam, GlideAttention.tree_part_fwd (qwen2_glide.py:331-359,
+            # "A non-triton version of tree_part_fwd"; SURVEY 8(c) shim 4) -- same signature, same call site (:326).
+            sa = m.glide.self_attn
+            sa.triton_tree_part_fwd = sa.tree_part_fwd
         ids = toy.make_prompt(cfg, plen, 100 + wseed)
         pl = torch.tensor([plen])
         trace = {"tree_mask": [], "all_spec": [], "llm_pred": [], "acc_ids": [], "acc_num": [], "cache_lens": []}

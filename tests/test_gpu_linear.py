@@ -38,6 +38,10 @@ def _mk(shape, seed, scale=1.0, dtype=torch.float16):
 
 SHAPES = [  # (N, K): Llama-3-8B projections (q/o, k/v, down), toy sizes, ragged N
     (4096, 4096), (1024, 4096), (4096, 14336), (512, 256), (512, 896), (100, 192), (264, 640),
+    # cfg4 LongChat-13B (hidden 5120, intermediate 13824): q/k/v/o, gate/up rows, down_proj
+    (5120, 5120), (13824, 5120), (5120, 13824),
+    # cfg5 QwQ-32B (hidden 5120, kv 1024, intermediate 27648): k/v, gate/up rows, down_proj
+    (1024, 5120), (27648, 5120), (5120, 27648),
 ]
 
 
@@ -63,6 +67,36 @@ def test_split_k_is_exact_and_deterministic(S, M):
     _check(y0.cpu(), ref_ops.linear(x, w), _acc_tol(x, w))
     for _ in range(5):                                   # arrival order of the workgroups must not matter
         assert torch.equal(ops.linear(x.cuda(), pw, n_splits=S), y0)
+
+
+def test_split_k_under_concurrent_hbm_load():
+    """The last-arriver split-K reduction must see every partial although the chip is busy: a side stream keeps
+    HBM and the fabric loaded (large copies) while split-K GEMMs of every projection shape run back to back; each
+    result must equal, bit for bit, the one computed on the idle chip.  (Round 1's workgroup-scope fence let the
+    slab counter overtake partial stores still in flight.)"""
+    from longspec_amd import ops
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")        # 1 GiB
+    big2 = torch.empty_like(big)
+    cases = []
+    for (N, K, M, S) in [(4096, 4096, 74, 0), (1024, 4096, 74, 8), (4096, 14336, 74, 0), (4096, 4096, 1, 0),
+                         (5120, 5120, 74, 0), (1024, 4096, 16, 5), (5120, 13824, 74, 0)]:
+        w, x = _mk((N, K), N + K + M, 0.03).cuda(), _mk((M, K), M + K + 1).cuda()
+        pw = ops.pack_weight(w)
+        kw = {"n_splits": S} if S else {}
+        cases.append((x, pw, kw, ops.linear(x, pw, **kw).clone()))
+    torch.cuda.synchronize()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                big2.copy_(big, non_blocking=True)
+        outs = []
+        for _ in range(40):
+            for (x, pw, kw, _want) in cases:
+                outs.append(ops.linear(x, pw, **kw))
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, cases[i % len(cases)][3]), f"split-K result changed under load (rep {rep}, launch {i})"
 
 
 def test_rows_do_not_depend_on_the_batch():
@@ -143,7 +177,7 @@ def test_qkv_rope_in_one_launch(dims, M, dtype, bias):
         ops.linear_multi(x, [ops.pack_weight(w, rope=True) for w in ws], bs)
 
 
-@pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512)])
+@pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512), (13824, 5120), (27648, 5120)])
 @pytest.mark.parametrize("M", [1, 16, 30, 74])
 def test_mlp_gate_up_silu(N, K, M):
     """silu(gate) * up with the reference's rounding points.  Each inner GEMM may be 1 ulp off the exact

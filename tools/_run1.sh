@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r2a
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu > gpurun_out/r2a/ops_v2.log 2>&1; echo "ops rc=$?" >> gpurun_out/r2a/ops_v2.log
+tail -5 gpurun_out/r2a/ops_v2.log
+for k in ws v2; do
+  LS_ATTN_KERNEL=$k timeout 300 python tools/bench_attn.py --L 16384 131072 --iters 30 > gpurun_out/r2a/bench_attn_$k.log 2>&1
+  cat gpurun_out/r2a/bench_attn_$k.log
+done
+timeout 600 python -m pytest tests/test_gpu_linear.py -x -q -m gpu -k "split_k or matches_oracle" > gpurun_out/r2a/linear.log 2>&1; tail -3 gpurun_out/r2a/linear.log
