@@ -25,7 +25,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _C
-from ._C import LS_NEW_DRAFT, LS_NEW_FLASH, LS_NEW_NONE, LS_NEW_TARGET, AttnDesc
+from ._C import LS_F16, LS_NEW_DRAFT, LS_NEW_FLASH, LS_NEW_NONE, LS_NEW_TARGET, AttnDesc
 
 _DT = {torch.float16: _C.LS_F16, torch.bfloat16: _C.LS_BF16}
 

@@ -69,6 +69,20 @@ def test_split_k_is_exact_and_deterministic(S, M):
         assert torch.equal(ops.linear(x.cuda(), pw, n_splits=S), y0)
 
 
+@pytest.mark.parametrize("N,K", [(152064, 5120), (32000, 5120)])
+@pytest.mark.parametrize("M", [1, 74])
+def test_lm_head_shapes_cfg4_cfg5(N, K, M):
+    """lm_head of QwQ-32B (cfg5: 152064 x 5120) and LongChat-13B (cfg4: 32000 x 5120) against the oracle's exact linear,
+    bf16 for the QwQ shape (how inference_qwq.py runs it).  The oracle evaluates 2000 sampled output columns (the full
+    152064-column product in fp64 on the host would take minutes)."""
+    from longspec_amd import ops
+    dtype = torch.bfloat16 if N == 152064 else torch.float16
+    w, x = _mk((N, K), N + K, 0.03, dtype), _mk((M, K), M + K, 1.0, dtype)
+    y = ops.linear(x.cuda(), ops.pack_weight(w.cuda())).cpu()
+    cols = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:2000]
+    _check(y[:, cols], ref_ops.linear(x, w[cols]), _acc_tol(x, w[cols]))
+
+
 def test_split_k_under_concurrent_hbm_load():
     """The last-arriver split-K reduction must see every partial although the chip is busy: a side stream keeps
     HBM and the fabric loaded (large copies) while split-K GEMMs of every projection shape run back to back; each
@@ -180,15 +194,24 @@ def test_qkv_rope_in_one_launch(dims, M, dtype, bias):
 @pytest.mark.parametrize("N,K", [(14336, 4096), (512, 256), (1024, 896), (1536, 512), (13824, 5120), (27648, 5120)])
 @pytest.mark.parametrize("M", [1, 16, 30, 74])
 def test_mlp_gate_up_silu(N, K, M):
-    """silu(gate) * up with the reference's rounding points.  Each inner GEMM may be 1 ulp off the exact
-    rounding on a rare element; SiLU (slope <= 1.1, then rounded) and the rounded product can carry that to
-    at most 4 ulp of the output (1 ulp relative on each factor, two more roundings)."""
+    """silu(gate) * up with the reference's rounding points.  Each inner GEMM may be 1 ulp off the exact rounding on a
+    rare element.  First-order propagation of those two input perturbations through out = round(round(silu(g)) * u):
+        |d out| <= |u| |silu'(g)| ulp(g) + |silu(g)| ulp(u)  +  the two output-side roundings (<= 2 ulp(out)),
+    which is <= 4 ulp(out) for g > -2 but MORE for strongly negative g, where silu is ill-conditioned in relative terms
+    (g = -4.35: |g silu'(g) / silu(g)| = 3.3, so one ulp of g moves the output by up to ~6 of its ulps -- met once in the
+    2 M outputs of the QwQ-32B shape).  The bound below is that sum; >= 98 % of the elements must be equal."""
     from longspec_amd import ops
     wg, wu, x = _mk((N, K), 61, 0.03), _mk((N, K), 62, 0.03), _mk((M, K), 63)
     got = ops.mlp_gate_up(x.cuda(), ops.pack_gate_up(wg.cuda(), wu.cuda())).cpu()
     want = ref_ops.mlp_gate_up(x, wg, wu)
+    gt, ut = ref_ops.linear(x, wg), ref_ops.linear(x, wu)                 # the exactly rounded projections
+    g64, u64 = gt.double(), ut.double()
+    sig = torch.sigmoid(g64)
+    dsilu = sig * (1.0 + g64 * (1.0 - sig))
+    bound = (u64.abs() * dsilu.abs() * _ulp(gt) + (g64 * sig).abs() * _ulp(ut)) * 1.001 + 2.001 * _ulp(want) + 1e-4
     diff = (got.double() - want.double()).abs()
-    assert bool((diff <= 4.001 * _ulp(want) + 1e-4).all()), f"max diff {diff.max().item():.3e}"
+    assert bool((diff <= bound).all()), f"max excess {(diff - bound).max().item():.3e}"
+    assert bool((diff <= 8.001 * _ulp(want) + 1e-4).all()), f"max diff {diff.max().item():.3e}"
     assert (got == want).double().mean().item() >= 0.98
 
 

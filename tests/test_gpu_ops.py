@@ -304,9 +304,10 @@ def test_target_tree_part_golden(ops, c):
     assert_close_f16(out, c["current_out"], atol=1.1e-3, frac=0.02, what="tree part")
 
 
-@pytest.mark.parametrize("H,Hkv", [(32, 8), (32, 32), (40, 8)])
+@pytest.mark.parametrize("H,Hkv", [(32, 8), (32, 32), (40, 8), (40, 40)])
 def test_verify_attention_model_shapes_vs_oracle(ops, H, Hkv):
-    """Llama-3-8B / Vicuna-7B / QwQ-32B head layouts, ragged L = 4096 + 37, a = 1 and 6."""
+    """Llama-3-8B / Vicuna-7B / QwQ-32B / LongChat-13B (cfg4: MHA, 40 heads) head layouts, ragged L = 4096 + 37,
+    a = 1 and 6."""
     for a, seed in ((1, 81), (6, 82)):
         q, k, v, kc, vc, tm = toy.verify_inputs(H, Hkv, 4096 + 37, seed, a=a)
         cl = torch.tensor([4096 + 37], dtype=torch.int32)
@@ -381,6 +382,48 @@ def test_tree_attention_triton_golden(ops, c):
     o, L = ops.tree_attention(g(c["q"]), g(c["k"]), g(c["v"]), g(c["mask"]))
     assert_close_f16(o, c["o"], atol=1.1e-3, frac=0.05, what="tree o")
     assert (L.cpu() - c["L"]).abs().max().item() <= 5e-6
+
+
+@pytest.mark.parametrize("H,Hkv,L", [(40, 8, 4096 + 37), (32, 8, 1000), (40, 40, 777)])
+@pytest.mark.parametrize("last_layer", [False, True])
+def test_verify_attention_bf16_vs_oracle(ops, H, Hkv, L, last_layer):
+    """bfloat16 LS_NEW_TARGET at operator level (cfg5: QwQ-32B runs in bf16, 40 query / 8 kv heads): hybrid verification
+    attention vs the oracle evaluated in bf16 -- one bf16 ulp at the output's magnitude (2^-8 relative: 8.5e-3 abs for
+    |o| ~ 1; twice that after the 16-bit merge `prefix_o*w + current_out*(1-w)`, llama.py:387), KV scatter bit-exact."""
+    q, k, v, kc, vc, tm = toy.verify_inputs(H, Hkv, L, 300 + H + Hkv, a=3)
+    q, k, v, kc, vc = (t.to(torch.bfloat16) for t in (q, k, v, kc, vc))
+    cl = torch.tensor([L], dtype=torch.int32)
+    kc_r, vc_r = kc.clone(), vc.clone()
+    ref = ref_ops.target_verify_attention(q, k, v, kc_r, vc_r, cl, tm, last_layer)
+    kc_g, vc_g = g(kc), g(vc)
+    out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), last_layer, kv_len_hint=L)
+    assert out.dtype == torch.bfloat16
+    assert_close_f16(out, ref, atol=1.7e-2, mean=1.5e-3, what=f"bf16 H={H}/{Hkv}")
+    assert torch.equal(kc_g.cpu(), kc_r) and torch.equal(vc_g.cpu(), vc_r)
+
+
+def test_full_size_properties_qwq_bf16_32k(ops):
+    """cfg5 at its own size: QwQ-32B head layout (40 / 8), bf16, 32768-token prefix -- split-count invariance and agreement
+    with a dense fp32 soft-max evaluated on the GPU by torch (bf16 output: one ulp = 2^-8 relative)."""
+    H, Hkv, R, L = 40, 8, 74, 32768
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    q = torch.randn(1, R, H, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    kc = torch.randn(1, L + 128, Hkv, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    vc = torch.randn(1, L + 128, Hkv, 128, generator=gen).to(torch.bfloat16).to(DEV)
+    cl = torch.tensor([L], dtype=torch.int32, device=DEV)
+    o_full, lse_full = ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L)
+    o_s, lse_s = ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L, n_splits=7)
+    assert (o_full.float() - o_s.float()).abs().max().item() <= 2e-3
+    assert (lse_full - lse_s).abs().max().item() <= 5e-5
+    g_ = H // Hkv
+    for h0 in range(0, H, 10):
+        qh = q[0, :, h0:h0 + 10].float().permute(1, 0, 2)
+        kh = kc[0, :L, h0 // g_:(h0 + 10) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        vh = vc[0, :L, h0 // g_:(h0 + 10) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        s_ = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(128)
+        ref = torch.matmul(torch.softmax(s_, -1), vh).permute(1, 0, 2)
+        assert (o_full[0, :, h0:h0 + 10].float() - ref).abs().max().item() <= 2e-3      # |o| ~ 0.02 at L = 32k
+        assert (lse_full[0, h0:h0 + 10] - torch.logsumexp(s_, -1)).abs().max().item() <= 2e-4
 
 
 # --------------------------------------------------------------------------- #
