@@ -262,6 +262,23 @@ int ls_tree_collapse(const int64_t* all_spec, const int64_t* all_llm_pred, const
                      void* k_cache, void* v_cache, int64_t kc_stride_b, int64_t kc_stride_s,
                      int row_elems, int dtype, void* stream);
 
+/* LlamaGlide.verify_stochastic (longspec/test/llama_glide.py:1177-1245), temperature > 0: the speculative-sampling walk down
+ * the draft tree, one workgroup per batch row.  all_spec [b,F] int64, tree_mask [b,F,F] int64, llm_logits [b,F,V] dtype
+ * (target logits; strides in elements), spec_logp [b,Fs,V] fp32 (draft log-probs of the non-leaf nodes).  The reference
+ * draws from Python's `random` and from torch.multinomial; both streams are handed in pre-drawn:
+ *   mt_words [b,n_words] uint32 = the next raw outputs of Python's Mersenne Twister (random.getrandbits(32)): one word per
+ *     random.choice attempt (>> (32 - bit_length(len))), two per random.random();  words_used [b] int32 = how many the walk
+ *     consumed (-1: the buffer was too short) so that the host can re-synchronise its generator;
+ *   exp_noise [b,V] dtype = torch.empty(V).exponential_(1): multinomial(p, 1) is argmax(p / noise) (ATen's one-sample path).
+ * acc_ids [b,max_acc] int64 zero padded (max_acc >= tree depth + 2), acc_num [b] int64; workspace: b*V floats.
+ * Kept from the reference on purpose: the acceptance ratio of child NODE s reads both distributions at vocabulary index s
+ * (:1222); target probabilities are rounded to dtype after every operation (:1186,1231-1235). */
+int ls_tree_verify_stochastic(const int64_t* all_spec, const int64_t* tree_mask, const void* llm_logits, int64_t logits_stride_b,
+                              int64_t logits_stride_r, const float* spec_logp, int64_t logp_stride_b, int64_t logp_stride_r,
+                              int b, int F, int Fs, int V, int dtype, float temperature, const uint32_t* mt_words, int n_words,
+                              const void* exp_noise, int64_t* acc_ids, int max_acc, int64_t* acc_num, int32_t* words_used,
+                              float* workspace, void* stream);
+
 /* End of the round (llama_glide.py:1093-1121): output_ids[z, emitted + j] = acc_ids[z, j] (j < acc_num);
  * state[z] = (acc_num, any(output_ids[z, :out_cap] == eos)) for the round's single host read; the tree
  * state reset (tree_mask = 0, column 0 = 1; all_spec = 0, all_spec[0] = last accepted id; logp_sum = 0);

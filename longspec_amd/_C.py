@@ -83,6 +83,8 @@ SYMBOLS = {
     "ls_tree_collapse": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _P]),
     "ls_tree_grow": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _I, _P, _P, _I, _P]),
     "ls_tree_verify_inputs": (C.c_int, [_P, _L, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "ls_tree_verify_stochastic": (C.c_int, [_P, _P, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P, _P, _I, _P, _P,
+                                            _P, _P]),
     "ls_tree_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _I, _P, _I, _L, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "ls_embed_rows": (C.c_int, [_P, _L, _I, _I, _P, _I, _P, _P]),
     "ls_chain_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _P, _P, _P, _P, _I, _L, _P, _P]),

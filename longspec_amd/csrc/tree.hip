@@ -315,6 +315,182 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const char* __restrict_
         *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src + o);
 }
 
+
+// ---- temperature > 0: LlamaGlide.verify_stochastic (llama_glide.py:1177-1245) ---------------------------------------
+// The speculative-sampling walk down the draft tree of ONE batch row per workgroup.  The reference draws from Python's
+// `random` (random.choice over the remaining children, random.random) and from torch.multinomial; the host hands the
+// kernel both streams pre-drawn -- `mt_words`: the next raw 32-bit outputs of the Mersenne Twister (random.choice(seq) =
+// seq[getrandbits(k) rejection-sampled below len(seq)], getrandbits(k <= 32) = one word >> (32 - k); random.random() =
+// ((w0 >> 5) * 2^26 + (w1 >> 6)) / 2^53), `exp_noise`: the Exponential(1) row of multinomial's one-sample fast path
+// (result = argmax(p / noise)) -- and reads back how many words were consumed.  Everything the reference keeps in the
+// activation dtype is rounded to it here after every operation (soft-max, p + 1e-9, the residual max(p - q, 0) / sum).
+// Reference quirk kept: the acceptance ratio of child node s reads both distributions at VOCABULARY index s (:1222).
+template <typename E>
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < TT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+template <typename E>
+__global__ __launch_bounds__(TT) void tree_verify_stochastic_kernel(
+    const int64_t* __restrict__ all_spec, const int64_t* __restrict__ tree_mask, const typename E::T* __restrict__ logits,
+    long lg_sb, long lg_sr, const float* __restrict__ logp, long lp_sb, long lp_sr, int F, int Fs, int V, float temperature,
+    const uint32_t* __restrict__ mt_words, int n_words, const typename E::T* __restrict__ noise, int64_t* __restrict__ acc_ids,
+    int max_acc, int64_t* __restrict__ acc_num, int32_t* __restrict__ words_used, float* __restrict__ prow_all) {
+    __shared__ int father[MAXF];
+    __shared__ int kids[MAXF];
+    __shared__ float red[TT / 64];
+    __shared__ int sh_n, sh_cur, sh_taken, sh_reject, sh_w, sh_bad;
+    __shared__ float sh_best;
+    __shared__ int sh_besti;
+    __shared__ long path[16];
+    const int z = blockIdx.x, tid = threadIdx.x;
+    const int64_t* mask = tree_mask + (long)z * F * F;
+    const typename E::T* lg = logits + (long)z * lg_sb;
+    const float* lp = logp + (long)z * lp_sb;
+    const uint32_t* words = mt_words + (long)z * n_words;
+    float* prow = prow_all + (long)z * V;
+    // fathers: the largest ancestor index other than the node itself (0 for the root)
+    for (int u = tid; u < F; u += TT) {
+        int f = 0;
+        for (int j = 0; j < F; ++j)
+            if (j != u && mask[(long)u * F + j] != 0) f = j;
+        father[u] = f;
+    }
+    if (tid == 0) {
+        sh_cur = 0;
+        sh_w = 0;
+        sh_bad = 0;
+        path[0] = all_spec[(long)z * F];
+    }
+    __syncthreads();
+    int n_path = 1;
+    int row_of = -1;                          // node whose (possibly residual) target distribution prow holds
+    float mq = 0.f, sq = 1.f;                 // soft-max statistics of the draft row of the current node
+    auto load_rows = [&](int node) {          // prow = softmax(logits[node] / T) in E;  (mq, sq) of softmax(logp[node] / T) in fp32
+        float m = -INFINITY;
+        for (int j = tid; j < V; j += TT) m = fmaxf(m, round_to<E>(E::to_f32(lg[(long)node * lg_sr + j]) / temperature));
+        m = block_reduce<E>(m, true, red);
+        float sm = 0.f;
+        for (int j = tid; j < V; j += TT) sm += expf(round_to<E>(E::to_f32(lg[(long)node * lg_sr + j]) / temperature) - m);
+        sm = block_reduce<E>(sm, false, red);
+        for (int j = tid; j < V; j += TT)
+            prow[j] = round_to<E>(expf(round_to<E>(E::to_f32(lg[(long)node * lg_sr + j]) / temperature) - m) / sm);
+        if (node < Fs) {
+            float m2 = -INFINITY;
+            for (int j = tid; j < V; j += TT) m2 = fmaxf(m2, lp[(long)node * lp_sr + j] / temperature);
+            m2 = block_reduce<E>(m2, true, red);
+            float s2 = 0.f;
+            for (int j = tid; j < V; j += TT) s2 += expf(lp[(long)node * lp_sr + j] / temperature - m2);
+            s2 = block_reduce<E>(s2, false, red);
+            mq = m2;
+            sq = s2;
+        }
+        __syncthreads();
+    };
+    auto qval = [&](int node, int j) -> float { return expf(lp[(long)node * lp_sr + j] / temperature - mq) / sq; };
+    while (true) {
+        const int cur = sh_cur;
+        if (tid == 0) {                       // children of cur in increasing node order
+            int n = 0;
+            for (int u = 0; u < F; ++u)
+                if (u != cur && father[u] == cur) kids[n++] = u;
+            sh_n = n;
+            sh_taken = -1;
+        }
+        __syncthreads();
+        if (sh_n == 0) break;
+        load_rows(cur);
+        row_of = cur;
+        while (true) {                        // draw children until one is accepted or none is left
+            if (tid == 0) {
+                int n = sh_n, w = sh_w;
+                sh_reject = -1;
+                if (n > 0) {
+                    const int k = 32 - __clz(n);
+                    unsigned r;
+                    do {
+                        if (w >= n_words) { sh_bad = 1; r = 0; break; }
+                        r = words[w++] >> (32 - k);
+                    } while (r >= (unsigned)n);
+                    const int s = kids[r];
+                    double rnd = 0.0;
+                    if (w + 2 <= n_words) {
+                        const unsigned a = words[w] >> 5, b2 = words[w + 1] >> 6;
+                        w += 2;
+                        rnd = ((double)a * 67108864.0 + (double)b2) * (1.0 / 9007199254740992.0);
+                    } else sh_bad = 1;
+                    const float pv = round_to<E>(prow[s] + 1e-9f);
+                    const float qv = qval(cur, s) + 1e-9f;
+                    const float ratio = pv / qv;
+                    if ((float)rnd <= ratio) sh_taken = s;
+                    else {
+                        sh_reject = s;
+                        int o = 0;
+                        for (int i = 0; i < n; ++i)
+                            if (kids[i] != s) kids[o++] = kids[i];
+                        sh_n = o;
+                    }
+                    sh_w = w;
+                }
+            }
+            __syncthreads();
+            if (sh_taken >= 0 || sh_reject < 0) break;
+            // residual distribution of the target at cur: max(p - q, 0), renormalised, every step rounded to E
+            float part = 0.f;
+            for (int j = tid; j < V; j += TT) {
+                float v = round_to<E>(prow[j] - qval(cur, j));
+                v = v > 0.f ? v : 0.f;
+                prow[j] = v;
+                part += v;
+            }
+            const float tot = round_to<E>(block_reduce<E>(part, false, red));
+            if (tot > 0.f)
+                for (int j = tid; j < V; j += TT) prow[j] = round_to<E>(prow[j] / tot);
+            __syncthreads();
+            if (sh_n == 0) break;
+        }
+        if (sh_taken < 0) break;
+        if (tid == 0) {
+            if (n_path < 15) path[n_path] = all_spec[(long)z * F + sh_taken];
+            sh_cur = sh_taken;
+        }
+        ++n_path;
+        __syncthreads();
+    }
+    const int cur = sh_cur;
+    if (row_of != cur) load_rows(cur);
+    // torch.multinomial(p, 1): arg-max of p / Exponential(1) noise in E, first maximum
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int j = tid; j < V; j += TT) {
+        const float v = round_to<E>(prow[j] / E::to_f32(noise[(long)z * V + j]));
+        if (v > best) { best = v; besti = j; }
+    }
+    const float gbest = block_reduce<E>(best, true, red);
+    if (tid == 0) sh_besti = 0x7fffffff;
+    __syncthreads();
+    if (best == gbest) atomicMin(&sh_besti, besti);
+    __syncthreads();
+    if (tid == 0) {
+        if (n_path < 15) path[n_path] = sh_besti == 0x7fffffff ? 0 : sh_besti;
+        ++n_path;
+        acc_num[z] = n_path;
+        for (int i = 0; i < max_acc; ++i) acc_ids[(long)z * max_acc + i] = i < n_path ? path[i] : 0;
+        words_used[z] = sh_bad ? -1 : sh_w;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,6 +579,35 @@ int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), (const char*)table, ids,
                        (long)vocab, hidden * 2, (char*)out);
     LS_CHECK_LAUNCH("embed_rows_kernel");
+    return LS_OK;
+}
+
+
+int ls_tree_verify_stochastic(const int64_t* all_spec, const int64_t* tree_mask, const void* llm_logits, int64_t logits_stride_b,
+                              int64_t logits_stride_r, const float* spec_logp, int64_t logp_stride_b, int64_t logp_stride_r,
+                              int b, int F, int Fs, int V, int dtype, float temperature, const uint32_t* mt_words, int n_words,
+                              const void* exp_noise, int64_t* acc_ids, int max_acc, int64_t* acc_num, int32_t* words_used,
+                              float* workspace, void* stream) {
+    if (!all_spec || !tree_mask || !llm_logits || !spec_logp || !mt_words || !exp_noise || !acc_ids || !acc_num || !words_used ||
+        !workspace)
+        LS_FAIL(LS_ERR_INVALID_ARG, "verify_stochastic: null argument");
+    if (b < 1 || F < 1 || F > MAXF || Fs < 1 || V < 1 || max_acc < 2 || max_acc > 15 || n_words < 3 || !(temperature > 0.f))
+        LS_FAIL(LS_ERR_INVALID_ARG, "verify_stochastic: b=%d F=%d Fs=%d V=%d max_acc=%d n_words=%d T=%g", b, F, Fs, V, max_acc,
+                n_words, (double)temperature);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == LS_F16)
+        hipLaunchKernelGGL(tree_verify_stochastic_kernel<ElemF16>, dim3(b), dim3(TT), 0, s, all_spec, tree_mask,
+                           static_cast<const _Float16*>(llm_logits), (long)logits_stride_b, (long)logits_stride_r, spec_logp,
+                           (long)logp_stride_b, (long)logp_stride_r, F, Fs, V, temperature, mt_words, n_words,
+                           static_cast<const _Float16*>(exp_noise), acc_ids, max_acc, acc_num, words_used, workspace);
+    else if (dtype == LS_BF16)
+        hipLaunchKernelGGL(tree_verify_stochastic_kernel<ElemBF16>, dim3(b), dim3(TT), 0, s, all_spec, tree_mask,
+                           static_cast<const __bf16*>(llm_logits), (long)logits_stride_b, (long)logits_stride_r, spec_logp,
+                           (long)logp_stride_b, (long)logp_stride_r, F, Fs, V, temperature, mt_words, n_words,
+                           static_cast<const __bf16*>(exp_noise), acc_ids, max_acc, acc_num, words_used, workspace);
+    else
+        LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
+    LS_CHECK_LAUNCH("tree_verify_stochastic_kernel");
     return LS_OK;
 }
 

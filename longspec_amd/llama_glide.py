@@ -449,8 +449,6 @@ class LlamaGlide(LlamaForCausalLM):
         and its KV kept sequence-sharded over the ranks (``_sharded_prefill``); decoding then runs replicated with one
         exchange per attention call.  Returns the same values on every rank."""
         assert input_ids is not None, "please give the input"
-        if temperature > 0:
-            raise NotImplementedError("temperature > 0 (verify_stochastic) is a 'next' row (SURVEY 8(f).4)")
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
         dev = input_ids.device
@@ -476,11 +474,11 @@ class LlamaGlide(LlamaForCausalLM):
             position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
             self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
                        cache_lens=lens.clone(), llm_kv_len=lens.clone(), exec_type="prefill")
-        st = self.begin_tree_decode(first, lens, P, tree_shape, max_gen_len, eos_id)
+        st = self.begin_tree_decode(first, lens, P, tree_shape, max_gen_len, eos_id, temperature=temperature)
         _sync(input_ids)
         start_time = time.time()
         for out_index in range(1, max_gen_len):
-            if not self.tree_round(st):
+            if not (self.tree_round_stochastic(st) if temperature > 0 else self.tree_round(st)):
                 break
         _sync(input_ids)
         elapsed_time = time.time() - start_time
@@ -516,7 +514,8 @@ class LlamaGlide(LlamaForCausalLM):
         self.glide.prefill_cache_only(hidden_states, self.model.rotary_emb(hidden_states, position_ids))
         return first
 
-    def begin_tree_decode(self, first_token, cache_lens, prompt_bound: int, tree_shape=None, max_gen_len=64, eos_id=151645):
+    def begin_tree_decode(self, first_token, cache_lens, prompt_bound: int, tree_shape=None, max_gen_len=64, eos_id=151645,
+                          temperature=0.0):
         """State of the round loop right after the two prefills (``llama_glide.py:927-991``).
         ``first_token`` [bsz] = the target's first generated token, ``cache_lens`` [bsz] int32 = valid
         rows of every KV cache, ``prompt_bound`` = host-side bound of it.  Also the entry point of
@@ -556,7 +555,18 @@ class LlamaGlide(LlamaForCausalLM):
         st.tree_mask[:, :, 0] = 1
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
         st.eos = self._stop_id(eos_id, "tree")
-        st.arange_g = torch.arange(gamma + 1, device=dev)[None, :]
+        st.arange_g = torch.arange(gamma + 2, device=dev)[None, :]
+        st.temperature = float(temperature)
+        if temperature > 0:
+            # stochastic verification (:1093-1102): the draft's log-probs of every tree node are kept (`spec_logits`, :964),
+            # up to gamma + 2 tokens come back per round, rounds run launch by launch (a host read inside)
+            st.spec_logits = None                      # allocated at the first lm_head call (vocabulary size)
+            st.acc_pad = torch.zeros((bsz, gamma + 2), dtype=torch.int64, device=dev)
+            st.acc_pad[:, 0] = first_token
+            st.acc_ids = st.acc_pad[:, :1]
+            st.use_graphs = False
+            st.input_len = cache_lens.clone()
+            st.d0_rows = 1                             # rows of the next draft step 0 = width of the last acc_ids
         return st
 
     def tree_round(self, st) -> bool:
@@ -676,9 +686,13 @@ class LlamaGlide(LlamaForCausalLM):
         ops = self.ops
         last_attn = self.model.layers[-1].self_attn
         acc_ids = st.acc_pad[:, :a]
-        # ---- D0: the a accepted tokens through the draft layer (:1003-1027)
-        hidden_states = self.model.embed_tokens(acc_ids)
-        position_ids = st.arange_g[:, :a] + st.draft_cache_lens[:, None]
+        # ---- D0: the a accepted tokens through the draft layer (:1003-1027).  At temperature > 0 the reference feeds the
+        # whole zero-padded acc_ids row (its width, not acc_num, :1003): the extra rows only write cache rows that are
+        # overwritten before they are read, but the ROW COUNT enters the bottom-right alignment of the causal cross-attention
+        # (row i sees llm_kv_len - sq + i keys), so it is reproduced.
+        n0 = a if st.temperature == 0 else st.d0_rows
+        hidden_states = self.model.embed_tokens(st.acc_pad[:, :n0])
+        position_ids = st.arange_g[:, :n0] + st.draft_cache_lens[:, None]
         position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                    llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
@@ -686,6 +700,10 @@ class LlamaGlide(LlamaForCausalLM):
         # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits
         logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
         vocab_size = logits.size(-1)
+        if st.temperature > 0:                         # spec_logits[:, 0] = current_logp (:1025, G8: log-probs, not logits)
+            if st.spec_logits is None:
+                st.spec_logits = torch.zeros((bsz, Fn, vocab_size), dtype=torch.float32, device=logits.device)
+            st.spec_logits[:, 0] = logits[:, 0].float().log_softmax(dim=-1)
         topk_logp, pred_ids = ops.logprob_topk(logits, None, cand[0])
         # the root's children (:1021-1027): tree_mask rows + diagonal, all_spec, log-prob sums, and
         # `draft_cache_lens += a - 1` -- one launch, which also hands back the next pass's positions and packed mask
@@ -701,7 +719,10 @@ class LlamaGlide(LlamaForCausalLM):
                                        llm_kv_len=st.target_cache_lens_for_draft, exec_type="tree_decoding",
                                        tree_mask=tree_mask[:, lo:mid, :mid], tree_mask_bits=mask_bits)
             # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
-            topk_logp_sum, topk_indices = ops.logprob_topk(self.lm_head(hidden_states), history_logp_sum[:, lo:mid], cand[ms])
+            level_logits = self.lm_head(hidden_states)
+            if st.temperature > 0:                     # spec_logits[:, lo:mid] = current_logp (:1074)
+                st.spec_logits[:, lo:mid] = level_logits.float().log_softmax(dim=-1)
+            topk_logp_sum, topk_indices = ops.logprob_topk(level_logits, history_logp_sum[:, lo:mid], cand[ms])
             # father = index // vocab, token = index % vocab, mask row = father's row + diagonal (:1056-1075)
             position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp_sum, topk_indices,
                                                     vocab_size, lo, mid, base=st.draft_cache_lens, want_next=ms + 1 < gamma)
@@ -711,6 +732,8 @@ class LlamaGlide(LlamaForCausalLM):
         hidden_states = self.model.forward(veri_spec, position_ids=position_ids, cache_lens=st.cache_lens,
                                            exec_type="tree_decoding", tree_mask_bits=mask_bits).last_hidden_state
         hidden_states = hidden_states[:, a - 1:a + Fn - 1]
+        if st.temperature > 0:
+            return self.lm_head(hidden_states)         # the stochastic branch continues in tree_round_stochastic
         all_llm_pred = ops.argmax_rows(self.lm_head(hidden_states))
         # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116); the accepted rows start at
         # cache_lens + a - 1 (:1104), the cache lengths themselves advance in the commit below
@@ -729,6 +752,49 @@ class LlamaGlide(LlamaForCausalLM):
         return ops.tree_commit(acc_pad, acc_num_t, st.output_ids, 0, st.eos, tree_mask, all_spec, history_logp_sum,
                                target_lens=st.cache_lens, target_add=a, draft_kv_lens=st.target_cache_lens_for_draft,
                                emitted_dev=st.emitted_dev)
+
+    def tree_round_stochastic(self, st) -> bool:
+        """One round at temperature > 0 (``llama_glide.py:997-1102,1110-1121``).  The draft passes and the verification pass
+        are those of ``tree_round``; acceptance is ``verify_stochastic``.  The bookkeeping follows the reference's T > 0
+        branch AS IT IS, which differs from its T = 0 branch (documented): ``cache_lens`` advances by
+        ``acc_num - 1`` only (no ``+= 1``), the accepted rows of the last layer's KV are NOT compacted, and the whole
+        zero-padded ``acc_ids`` row is written to ``output_ids`` at ``cache_lens - input_len`` -- so later rounds overwrite
+        part of what earlier rounds wrote.  Reproduced token for token (tests/golden/verify_stochastic.npz)."""
+        a = st.a
+        if a + st.Fn - 1 > st.R:
+            # the reference fails here too: gamma + 2 accepted tokens do not fit its veri_spec buffer (:1081)
+            raise RuntimeError(f"stochastic round: {a} accepted tokens + {st.Fn - 1} tree nodes exceed the {st.R}-row "
+                               f"verification batch (the reference raises at llama_glide.py:1081 in the same state)")
+        self._set_hints(st.P + st.output_ids.size(1) + st.R, st.P + st.output_ids.size(1) + st.Fn)
+        llm_logits = self._round_device(st, a)                               # [bsz, Fn, V]
+        st.cache_lens += a - 1                                               # :1094
+        acc_ids, acc_num = self.verify_stochastic(st.all_spec, st.tree_mask, llm_logits, st.spec_logits, st.temperature)
+        W = acc_ids.size(-1)
+        cols = (st.cache_lens - st.input_len).long().unsqueeze(1) + torch.arange(W, device=acc_ids.device)[None, :]
+        st.output_ids[torch.arange(st.bsz, device=acc_ids.device)[:, None], cols] = acc_ids          # :1102
+        st.target_cache_lens_for_draft += acc_num.to(torch.int32)            # :1110
+        n = int(acc_num[0])
+        st.count += n - 1
+        st.num += st.bsz
+        st.tree_mask.fill_(0)
+        st.tree_mask[:, :, 0] = 1
+        st.all_spec.fill_(0)
+        st.all_spec[:, 0] = acc_ids[:, n - 1]
+        st.history_logp_sum.zero_()
+        st.acc_pad.zero_()
+        st.acc_pad[:, :W] = acc_ids
+        st.acc_ids = st.acc_pad[:, :n]
+        st.a = n
+        st.d0_rows = W
+        if int((st.cache_lens + acc_num.to(torch.int32) - st.input_len).max()) + st.gamma + 2 > st.output_ids.size(1):   # :1118
+            return False
+        if st.eos is not None and bool(st.output_ids.eq(st.eos).any()):      # :1120
+            return False
+        return True
+
+    def verify_stochastic(self, input_ids, tree_mask, p_llm, p_ssm, temperature):               # :1177-1245
+        """Drop-in for ``LlamaGlide.verify_stochastic``: (acc_ids [bsz, depth + 2] zero padded, acc_num [bsz])."""
+        return self.ops.verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature)
 
     # ------------------------------------------------------------------------------------------
     def tree_verification(self, input_ids, output_ids, tree_mask, cache_lens, non_leaf_len):      # :1128-1175

@@ -791,6 +791,70 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len: i
     return acc_ids, acc_num, dbl, imap
 
 
+MT_WORDS = 512           # raw Mersenne-Twister words handed to a stochastic verification (a walk uses <= ~3 per child drawn)
+
+
+def tree_verify_stochastic(all_spec, tree_mask, llm_logits, spec_logp, temperature: float, mt_words, exp_noise, max_acc: int):
+    """``LlamaGlide.verify_stochastic`` (``llama_glide.py:1177-1245``) on the device with pre-drawn randomness
+    (``ls_tree_verify_stochastic``): returns (acc_ids [b,max_acc], acc_num [b], words_used [b] int32)."""
+    _dev(all_spec, tree_mask, llm_logits, spec_logp, mt_words, exp_noise)
+    b, Fn = all_spec.shape
+    V = llm_logits.shape[-1]
+    if llm_logits.stride(-1) != 1 or spec_logp.stride(-1) != 1 or spec_logp.dtype != torch.float32:
+        raise ValueError("logits must be contiguous in the vocabulary, draft log-probs fp32")
+    if mt_words.dtype != torch.int32 and mt_words.dtype != torch.uint32:
+        raise TypeError("mt_words: 32-bit words")
+    all_spec, tree_mask = all_spec.contiguous(), tree_mask.contiguous()
+    exp_noise = exp_noise.to(llm_logits.dtype).contiguous()
+    dev = all_spec.device
+    acc_ids = torch.empty((b, max_acc), dtype=torch.int64, device=dev)
+    acc_num = torch.empty((b,), dtype=torch.int64, device=dev)
+    used = torch.empty((b,), dtype=torch.int32, device=dev)
+    ws = torch.empty((b, V), dtype=torch.float32, device=dev)
+    _C.check(_C.load().ls_tree_verify_stochastic(
+        all_spec.data_ptr(), tree_mask.data_ptr(), llm_logits.data_ptr(), llm_logits.stride(0), llm_logits.stride(1),
+        spec_logp.data_ptr(), spec_logp.stride(0), spec_logp.stride(1), b, Fn, spec_logp.shape[1], V, _dtype(llm_logits),
+        float(temperature), mt_words.data_ptr(), mt_words.shape[-1], exp_noise.data_ptr(), acc_ids.data_ptr(), max_acc,
+        acc_num.data_ptr(), used.data_ptr(), ws.data_ptr(), _stream()), "ls_tree_verify_stochastic")
+    return acc_ids, acc_num, used
+
+
+stochastic_noise_fn = None     # tests replay the reference's CPU generator: fn(V, dtype, device) -> Exponential(1) row
+
+
+def verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature: float):
+    """``LlamaGlide.verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature)`` (``llama_glide.py:1177-1245``).
+    The randomness is the reference's: Python's ``random`` stream (choice / random) and one ``exponential_`` row per batch
+    element from torch (what ``torch.multinomial(p, 1)`` draws); the walk itself runs on the device.  After the launch
+    Python's generator is advanced by exactly the words the walk consumed.  One host read per batch row."""
+    import random
+    import numpy as np
+    b, Fn = input_ids.shape
+    V = p_llm.shape[-1]
+    width = int(tree_mask.sum(-1).max()) + 1                      # :1193 (a host read in the reference too)
+    acc_ids = input_ids.new_zeros((b, width))
+    acc_num = input_ids.new_zeros((b,))
+    for z in range(b):
+        state = random.getstate()
+        words = np.array([random.getrandbits(32) for _ in range(MT_WORDS)], dtype=np.uint32).view(np.int32)
+        mt = torch.from_numpy(words).to(input_ids.device)[None]
+        if stochastic_noise_fn is not None:
+            noise = stochastic_noise_fn(V, p_llm.dtype, p_llm.device)
+        else:
+            noise = torch.empty((V,), dtype=p_llm.dtype, device=p_llm.device).exponential_(1)
+        ids, num, used = tree_verify_stochastic(input_ids[z:z + 1], tree_mask[z:z + 1], p_llm[z:z + 1], p_ssm[z:z + 1],
+                                                temperature, mt, noise[None], max(width, 2))
+        used = int(used[0])
+        if used < 0:
+            raise RuntimeError("verify_stochastic: the pre-drawn random words were exhausted")
+        random.setstate(state)
+        for _ in range(used):
+            random.getrandbits(32)
+        acc_ids[z] = ids[0, :width]
+        acc_num[z] = num[0]
+    return acc_ids, acc_num
+
+
 def tree_commit(acc_ids, acc_num, output_ids, emitted: int, eos: Optional[int], tree_mask, all_spec, logp_sum,
                 target_lens: Optional[torch.Tensor] = None, target_add: int = 0,
                 draft_kv_lens: Optional[torch.Tensor] = None, emitted_dev: Optional[torch.Tensor] = None) -> torch.Tensor:

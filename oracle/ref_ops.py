@@ -503,3 +503,85 @@ def lse_merge(o_parts, lse_parts):
         o = o + op.float() * w[i].transpose(0, 1).unsqueeze(-1)
     o = o / torch.where(den == 0, torch.ones_like(den), den).transpose(0, 1).unsqueeze(-1)
     return o, m_safe + torch.log(den)
+
+
+# --------------------------------------------------------------------------- #
+# temperature > 0: stochastic tree verification
+# --------------------------------------------------------------------------- #
+class HostDraws:
+    """The two random streams ``verify_stochastic`` consumes, in the reference's call order: Python's ``random``
+    (``random.choice`` over the remaining children, then ``random.random``) and torch's default generator
+    (``torch.multinomial`` of one sample = arg-max of ``p / Exponential(1)`` noise, ATen's fast path)."""
+
+    def choice(self, seq):
+        import random
+        return random.choice(seq)
+
+    def random(self):
+        import random
+        return random.random()
+
+    def multinomial(self, p_row):
+        return int(torch.multinomial(p_row, num_samples=1).item())
+
+
+def tree_fathers(tree_mask: torch.Tensor) -> torch.Tensor:
+    """Father of every tree node (``llama_glide.py:1188-1191``): the largest ancestor index other than the node itself,
+    0 for the root -- ``((mask - I) * arange).argmax(-1)``."""
+    b, Fn, _ = tree_mask.shape
+    eye = torch.eye(Fn, dtype=tree_mask.dtype)[None]
+    return ((tree_mask - eye) * torch.arange(Fn)[None, None, :]).argmax(dim=-1)
+
+
+def verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature: float, draws=None):
+    """``LlamaGlide.verify_stochastic`` (``longspec/test/llama_glide.py:1177-1245``), speculative-sampling walk
+    down the draft tree.  input_ids [b,F] int64 (tree node tokens), tree_mask [b,F,F], p_llm [b,F,V] target LOGITS in
+    the activation dtype, p_ssm [b,Fs,V] fp32 draft log-probs (Fs >= number of non-leaf nodes), temperature > 0.
+    Returns (acc_ids [b, max depth + 2] zero padded, acc_num [b]).
+
+    Reference behaviour kept on purpose (documented):
+    * the acceptance ratio of child node ``s`` reads the two distributions at vocabulary index ``s`` -- the child's NODE
+      index, not its token id (``:1222``);
+    * the target probabilities stay in the activation dtype: ``softmax(logits / T)`` is fp16, ``p + 1e-9`` is a no-op in
+      fp16 unless p == 0, every residual update ``max(p - q, 0) / sum`` is rounded to fp16 (``:1231-1235``);
+    * ``r <= ratio`` compares in fp32 (Python float against a 0-dim fp32 tensor).
+    """
+    draws = draws or HostDraws()
+    b, Fn, _ = tree_mask.shape
+    pl = torch.softmax(p_llm / temperature, dim=-1)                # activation dtype
+    ps = torch.softmax(p_ssm / temperature, dim=-1)                # fp32
+    fathers = tree_fathers(tree_mask)
+    width = int(tree_mask.sum(-1).max()) + 1
+    acc_ids = input_ids.new_zeros((b, width))
+    acc_num = input_ids.new_zeros(b)
+    eps = 1e-9
+    for z in range(b):
+        path = [int(input_ids[z, 0])]
+        cur = 0
+        while True:
+            kids = [u for u in range(Fn) if u != cur and int(fathers[z, u]) == cur]
+            if not kids:
+                break
+            taken = None
+            while kids:
+                s = draws.choice(kids)
+                r = draws.random()
+                ratio = (pl[z, cur, s] + eps) / (ps[z, cur, s] + eps)            # 16-bit / fp32 -> fp32
+                if bool(torch.tensor(r, dtype=ratio.dtype) <= ratio):
+                    taken = s
+                    break
+                kids.remove(s)
+                row = (pl[z, cur, :] - ps[z, cur, :]).to(pl.dtype)                # residual, rounded to the activation dtype
+                row = torch.clamp(row, min=0)
+                tot = row.sum()
+                if tot > 0:
+                    row = row / tot
+                pl[z, cur, :] = row
+            if taken is None:
+                break
+            path.append(int(input_ids[z, taken]))
+            cur = taken
+        path.append(draws.multinomial(pl[z, cur, :]))
+        acc_num[z] = len(path)
+        acc_ids[z, :len(path)] = torch.tensor(path, dtype=acc_ids.dtype)
+    return acc_ids, acc_num

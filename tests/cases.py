@@ -148,3 +148,44 @@ def baseline_runs():
         for k in ("vanilla_torch_num", "magicdec_count", "magicdec_num"):
             d[k] = int(g[f"{name}_{k}"])
         yield d
+
+
+def stochastic_inputs(ci):
+    """Seeded inputs of verify_stochastic unit case ci (same construction as tests/golden/make_golden.py)."""
+    shapes = [[4, 16, 16, 16, 16]] * 12 + [[2, 2, 2]] * 4 + [[4, 4]] * 3 + [[1, 1, 1, 1, 1, 1]] * 3 + [[3]] * 2
+    shape = shapes[ci]
+    parents = toy.random_beam_tree(shape, 9500 + ci)
+    mask = toy.tree_mask_from_parents(parents)
+    Fn = mask.shape[0]
+    V = 160
+    g = torch.Generator().manual_seed(9600 + ci)
+    spec = torch.randint(2, V, (1, Fn), generator=g)
+    logits = (torch.randn(1, Fn, V, generator=g) * 2.0).to(torch.float16)
+    spec_logp = (torch.randn(1, Fn, V, generator=g) * 2.0).log_softmax(dim=-1)
+    temperature = [0.5, 1.0, 1.3, 0.8][ci % 4]
+    return shape, spec, torch.from_numpy(mask)[None].to(torch.int64), logits, spec_logp, temperature
+
+
+def stochastic_cases():
+    g = load_golden("verify_stochastic")
+    for ci in range(int(g["n_cases"])):
+        shape, spec, mask, logits, spec_logp, T = stochastic_inputs(ci)
+        assert toy.checksum(spec, mask, logits, spec_logp) == cksum_str(g[f"c{ci}_in_checksum"]), "RNG drift: regenerate goldens"
+        yield dict(name=f"c{ci}", ci=ci, shape=shape, spec=spec, mask=mask, logits=logits, spec_logp=spec_logp, T=T,
+                   acc_ids=_t(g[f"c{ci}_acc_ids"]), acc_num=_t(g[f"c{ci}_acc_num"]), after_random=float(g[f"c{ci}_after_random"]))
+
+
+def stochastic_runs():
+    g = load_golden("verify_stochastic")
+    for name in [str(x) for x in g["runs"]]:
+        over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
+        cfg = toy.toy_config(**over)
+        wseed = int(g[f"{name}_wseed"])
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=float(g[f"{name}_agreement"]))
+        assert toy.state_checksum(tgt) + toy.state_checksum(drf) == cksum_str(g[f"{name}_weights_checksum"]), \
+            "RNG drift: regenerate goldens"
+        yield dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]), wseed=wseed,
+                   prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]),
+                   tree_shape=[int(x) for x in g[f"{name}_tree_shape"]], temperature=float(g[f"{name}_temperature"]),
+                   out=_t(g[f"{name}_out"]), count=int(g[f"{name}_count"]), num=int(g[f"{name}_num"]),
+                   tr_acc_ids=_t(g[f"{name}_tr_acc_ids"]), tr_acc_num=_t(g[f"{name}_tr_acc_num"]), family="llama")

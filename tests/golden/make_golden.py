@@ -322,6 +322,84 @@ def gen_tree_verification(llama_glide):
     save("tree_verification", n_cases=n, **arrays)
 
 
+
+# --------------------------------------------------------------------------- #
+# G-h: verify_stochastic (temperature > 0), the function and the generate loop around it.  The reference draws from
+# Python's `random` (random.choice / random.random) and from torch's default generator (torch.multinomial): both are
+# seeded here, and a replay with the same seeds must consume them in the same order.
+# --------------------------------------------------------------------------- #
+def stochastic_case_inputs(ci):
+    """Seeded inputs of unit case ci -- shared with tests/cases.py (the fixture stores only seeds, a checksum and outputs)."""
+    shapes = [[4, 16, 16, 16, 16]] * 12 + [[2, 2, 2]] * 4 + [[4, 4]] * 3 + [[1, 1, 1, 1, 1, 1]] * 3 + [[3]] * 2
+    shape = shapes[ci]
+    parents = toy.random_beam_tree(shape, 9500 + ci)
+    mask = toy.tree_mask_from_parents(parents)
+    Fn = mask.shape[0]
+    V = 160
+    g = torch.Generator().manual_seed(9600 + ci)
+    spec = torch.randint(2, V, (1, Fn), generator=g)
+    logits = (torch.randn(1, Fn, V, generator=g) * 2.0).to(torch.float16)
+    spec_logp = (torch.randn(1, Fn, V, generator=g) * 2.0).log_softmax(dim=-1)
+    temperature = [0.5, 1.0, 1.3, 0.8][ci % 4]
+    return shape, spec, torch.from_numpy(mask)[None].to(torch.int64), logits, spec_logp, temperature
+
+
+N_STOCHASTIC = 24
+
+
+def gen_verify_stochastic(llama, llama_glide):
+    import random
+    arrays = {}
+    for ci in range(N_STOCHASTIC):
+        shape, spec, mask, logits, spec_logp, T = stochastic_case_inputs(ci)
+        ns = SimpleNamespace(range_tensor=torch.arange(0, 1024)[None, :], diag_matrix=torch.eye(1024, dtype=torch.int64)[None])
+        random.seed(5000 + ci)
+        torch.manual_seed(6000 + ci)
+        acc_ids, acc_num = llama_glide.LlamaGlide.verify_stochastic(ns, input_ids=spec, tree_mask=mask, p_llm=logits.clone(),
+                                                                    p_ssm=spec_logp.clone(), temperature=T)
+        t = f"c{ci}"
+        arrays.update({f"{t}_acc_ids": acc_ids, f"{t}_acc_num": acc_num,
+                       f"{t}_after_random": random.random(),          # where the Python stream stands afterwards
+                       f"{t}_in_checksum": np.frombuffer(toy.checksum(spec, mask, logits, spec_logp).encode(), dtype=np.uint8)})
+        print(f"[stochastic c{ci}] shape={shape} T={T} acc_num={int(acc_num[0])} acc_ids={acc_ids[0].tolist()}")
+    # end to end: tree_spec_generate(temperature > 0) on two toy models
+    for name, over, wseed, agree, plen, glen, shape, T in [
+            ("t_mixed", {}, 13, 0.05, 120, 40, [4, 16, 16, 16, 16], 0.8),
+            ("t_gqa", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 15, 0.05, 90, 32, [4, 16, 16, 16, 16], 1.0)]:
+        cfg = toy.toy_config(**over)
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
+        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        install_triton_stubs()
+        ids = toy.make_prompt(cfg, plen, 100 + wseed)
+        pl = torch.tensor([plen])
+        trace = {"acc_ids": [], "acc_num": []}
+        orig = m.verify_stochastic
+
+        def spy(*a, _orig=orig, _tr=trace, **k):
+            r = _orig(*a, **k)
+            pad = torch.full((1, 8), -1, dtype=torch.int64)
+            pad[:, :r[0].shape[1]] = r[0]
+            _tr["acc_ids"].append(pad)
+            _tr["acc_num"].append(r[1].clone())
+            return r
+
+        m.verify_stochastic = spy
+        random.seed(7000 + wseed)
+        torch.manual_seed(8000 + wseed)
+        with torch.inference_mode():
+            out, count, num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=shape, max_gen_len=glen, temperature=T)
+        print(f"[{name}] T={T} count={int(count)} num={int(num)} rounds={len(trace['acc_num'])}")
+        arrays.update({
+            f"{name}_cfg_keys": np.array(sorted(over.keys()), dtype="U32"),
+            f"{name}_cfg_vals": np.array([over[k] for k in sorted(over.keys())], dtype=np.int64),
+            f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
+            f"{name}_tree_shape": np.array(shape), f"{name}_temperature": T,
+            f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
+            f"{name}_prompt": ids, f"{name}_out": out, f"{name}_count": int(count), f"{name}_num": int(num),
+            f"{name}_tr_acc_ids": torch.cat(trace["acc_ids"], 0), f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
+        })
+    save("verify_stochastic", n_cases=N_STOCHASTIC, runs=np.array(["t_mixed", "t_gqa"], dtype="U32"), **arrays)
+
 # --------------------------------------------------------------------------- #
 # G-g: RMSNorm / RoPE from transformers
 # --------------------------------------------------------------------------- #
@@ -621,6 +699,9 @@ def main():
     llama, llama_glide, triton_tree_attn, train_llama = import_reference()
     if "--only-baselines" in sys.argv:
         gen_baselines(llama, llama_glide)
+        return
+    if "--only-stochastic" in sys.argv:
+        gen_verify_stochastic(llama, llama_glide)
         return
     if "--only-qwen2-bf16" in sys.argv:
         gen_generate(llama, llama_glide, family="qwen2_bf16")

@@ -240,3 +240,7 @@ def logprob_topk(logits, history, k):
 
 def argmax_rows(logits):
     return logits.argmax(dim=-1)
+
+
+def verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature):
+    return ref_ops.verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature)

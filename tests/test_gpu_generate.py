@@ -116,3 +116,37 @@ def test_bf16_generate_matches_reference(run):
     assert torch.equal(t_out[0, :n].cpu(), run["vanilla_out"][0, :n])                 # lossless
     assert torch.equal(t_out.cpu(), run["tree_out"])
     assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
+
+
+@pytest.mark.parametrize("run", list(cases.stochastic_runs()), ids=lambda r: r["name"])
+def test_tree_spec_generate_with_temperature_matches_reference(run):
+    """temperature > 0 end to end on the HIP kernels: the reference's seeded run of
+    tree_spec_generate(temperature=T) -- output_ids, count, num and every round's (acc_ids, acc_num) -- token for token."""
+    import random
+    from longspec_amd import ops
+    m = build(run)
+    trace = {"ids": [], "num": []}
+    orig = m.verify_stochastic
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        pad = torch.full((1, 8), -1, dtype=torch.int64)
+        pad[:, :r[0].shape[1]] = r[0].cpu()
+        trace["ids"].append(pad)
+        trace["num"].append(r[1].cpu().clone())
+        return r
+
+    m.verify_stochastic = spy
+    ops.stochastic_noise_fn = lambda V, dtype, device: torch.empty(V, dtype=dtype).exponential_(1).to(device)
+    try:
+        random.seed(7000 + run["wseed"])
+        torch.manual_seed(8000 + run["wseed"])
+        out, count, num, _, _ = m.tree_spec_generate(run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"),
+                                                     tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"],
+                                                     temperature=run["temperature"])
+    finally:
+        ops.stochastic_noise_fn = None
+    assert torch.equal(torch.cat(trace["num"], 0), run["tr_acc_num"])
+    assert torch.equal(torch.cat(trace["ids"], 0), run["tr_acc_ids"])
+    assert (int(count), int(num)) == (run["count"], run["num"])
+    assert torch.equal(out.cpu(), run["out"])

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import cases
 import oracle_ops
 
 pytestmark = pytest.mark.gpu
@@ -228,3 +229,51 @@ def test_largest_tree_all_operators(ops):
     st_d = ops.tree_commit(ids_d, num_d, out_d, 5, 31999, tm_d, spec_d, logp_d, target_lens=g(tl.clone()), target_add=a)
     assert torch.equal(st_c, st_d.cpu()) and torch.equal(out_c, out_d.cpu())
     assert torch.equal(tm, tm_d.cpu()) and torch.equal(spec, spec_d.cpu())
+
+
+# --------------------------------------------------------------------------- #
+# temperature > 0: ls_tree_verify_stochastic
+# --------------------------------------------------------------------------- #
+def _cpu_noise(V, dtype, device):
+    """torch.multinomial(p, 1) on the reference's (CPU) generator = one exponential_ row of p's dtype."""
+    return torch.empty(V, dtype=dtype).exponential_(1).to(device)
+
+
+@pytest.mark.parametrize("c", list(cases.stochastic_cases()), ids=lambda c: c["name"])
+def test_verify_stochastic_golden(c):
+    """The device walk with the reference's random streams (Python's generator seeded like the golden run, the
+    Exponential(1) row of torch.multinomial drawn from the CPU generator) == LlamaGlide.verify_stochastic of the
+    reference, token for token; Python's stream ends where the reference left it."""
+    import random
+    from longspec_amd import ops
+    ops.stochastic_noise_fn = _cpu_noise
+    try:
+        random.seed(5000 + c["ci"])
+        torch.manual_seed(6000 + c["ci"])
+        acc_ids, acc_num = ops.verify_stochastic(c["spec"].cuda(), c["mask"].cuda(), c["logits"].cuda(), c["spec_logp"].cuda(), c["T"])
+        assert torch.equal(acc_num.cpu(), c["acc_num"])
+        assert torch.equal(acc_ids.cpu(), c["acc_ids"])
+        assert random.random() == c["after_random"]
+    finally:
+        ops.stochastic_noise_fn = None
+
+
+def test_verify_stochastic_bf16_and_batch_vs_oracle():
+    """bf16 and bsz = 2 against the oracle restatement with the same draws."""
+    import random
+    from longspec_amd import ops
+    from oracle import ref_ops
+    ops.stochastic_noise_fn = _cpu_noise
+    try:
+        ins = [cases.stochastic_inputs(ci) for ci in (1, 5)]
+        spec = torch.cat([i[1] for i in ins]); mask = torch.cat([i[2] for i in ins])
+        logits = torch.cat([i[3] for i in ins]).to(torch.bfloat16); logp = torch.cat([i[4] for i in ins])
+        random.seed(11); torch.manual_seed(12)
+        want_ids, want_num = ref_ops.verify_stochastic(spec, mask, logits.clone(), logp.clone(), 0.9)
+        after = random.random()
+        random.seed(11); torch.manual_seed(12)
+        got_ids, got_num = ops.verify_stochastic(spec.cuda(), mask.cuda(), logits.cuda(), logp.cuda(), 0.9)
+        assert torch.equal(got_num.cpu(), want_num) and torch.equal(got_ids.cpu(), want_ids)
+        assert random.random() == after
+    finally:
+        ops.stochastic_noise_fn = None

@@ -123,3 +123,32 @@ def test_bf16_generate_matches_reference(run):
     assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
     n = int(t_count) + int(t_num)
     assert torch.equal(t_out[0, :n], run["vanilla_out"][0, :n])          # lossless
+
+
+@pytest.mark.parametrize("run", list(cases.stochastic_runs()), ids=lambda r: r["name"])
+def test_tree_spec_generate_with_temperature_matches_reference(run):
+    """temperature > 0 end to end: the host loop around verify_stochastic -- including the reference's own
+    T > 0 bookkeeping (no KV compaction, cache_lens without the +1, whole padded acc_ids rows written to output_ids) --
+    replays the reference's seeded run token for token: output_ids, count, num and every round's (acc_ids, acc_num)."""
+    import random
+    m = build(run)
+    trace = {"ids": [], "num": []}
+    orig = m.verify_stochastic
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        pad = torch.full((1, 8), -1, dtype=torch.int64)
+        pad[:, :r[0].shape[1]] = r[0]
+        trace["ids"].append(pad)
+        trace["num"].append(r[1].clone())
+        return r
+
+    m.verify_stochastic = spy
+    random.seed(7000 + run["wseed"])
+    torch.manual_seed(8000 + run["wseed"])
+    out, count, num, _, _ = m.tree_spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), tree_shape=run["tree_shape"],
+                                                 max_gen_len=run["max_gen_len"], temperature=run["temperature"])
+    assert torch.equal(torch.cat(trace["num"], 0), run["tr_acc_num"])
+    assert torch.equal(torch.cat(trace["ids"], 0), run["tr_acc_ids"])
+    assert (int(count), int(num)) == (run["count"], run["num"])
+    assert torch.equal(out, run["out"])

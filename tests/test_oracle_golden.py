@@ -151,3 +151,17 @@ def test_lse_merge_equals_joint_softmax():
         lses.append(l[0])
     o, lse = ref_ops.lse_merge(parts, lses)
     assert _maxdiff(o, full[0]) <= 2e-3 and _maxdiff(lse, lse_full[0]) <= 1e-5
+
+
+@pytest.mark.parametrize("c", list(cases.stochastic_cases()), ids=lambda c: c["name"])
+def test_verify_stochastic_matches_reference(c):
+    """temperature > 0: the restatement replays the reference's accept / reject walk token for token when
+    Python's and torch's generators are seeded like the golden run -- and leaves the Python stream where the reference
+    left it (same number of draws)."""
+    import random
+    random.seed(5000 + c["ci"])
+    torch.manual_seed(6000 + c["ci"])
+    acc_ids, acc_num = ref_ops.verify_stochastic(c["spec"], c["mask"], c["logits"].clone(), c["spec_logp"].clone(), c["T"])
+    assert torch.equal(acc_num, c["acc_num"])
+    assert torch.equal(acc_ids, c["acc_ids"])
+    assert random.random() == c["after_random"]
