@@ -244,8 +244,16 @@ class LlamaGlide(LlamaForCausalLM):
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
+    def _clear_shard(self):
+        """A shard set by an earlier ``tree_spec_generate(shard=...)`` on this object must not leak into loops that
+        prefill a full, unsharded cache."""
+        for layer in self.model.layers:
+            layer.self_attn.shard = None
+        self.glide.cross_attn.shard = None
+
     def vanilla_generate(self, input_ids, prompt_length, max_gen_len=64, eos_id=151645):       # :552-585
         assert input_ids is not None, "please give the input"
+        self._clear_shard()
         bsz = input_ids.size(0)
         output_ids = input_ids.new_zeros((bsz, max_gen_len))
         self.set_max_gen_len(max_gen_len)
@@ -261,17 +269,32 @@ class LlamaGlide(LlamaForCausalLM):
         eos = self._stop_id(eos_id, "vanilla")
         _sync(input_ids)
         start_time = time.time()
+        on_gpu = input_ids.is_cuda
+        marks = []                      # per-step completion marks: the time of steps decoded past the first EOS is not counted
+        if on_gpu:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         vs = self.begin_vanilla_decode(output_ids, cache_lens, input_len.int(), P)
         for step in range(1, max_gen_len):
             self.vanilla_step(vs)
             num += bsz
+            if on_gpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+            else:
+                marks.append(time.time() - start_time)
+            # the reference reads the EOS test back after every token (:578); here every 16th, and the result is then cut
+            # back to what the reference would have returned -- tokens, `num` AND elapsed time
             if eos is not None and (step % 16 == 0 or step == max_gen_len - 1):
                 if bool((output_ids[:, :step + 1].eq(eos)).any()):
                     break
         _sync(input_ids)
         elapsed_time = time.time() - start_time
         if eos is not None:
-            output_ids, num = _truncate_after_eos_vanilla(output_ids, num, eos, bsz)
+            output_ids, num, stop = _truncate_after_eos_vanilla(output_ids, num, eos, bsz)
+            if stop is not None and stop < len(marks):
+                elapsed_time = ev0.elapsed_time(marks[stop - 1]) * 1e-3 if on_gpu else marks[stop - 1]
         return output_ids, num, elapsed_time
 
     # ------------------------------------------------------------------------------------------
@@ -349,8 +372,10 @@ class LlamaGlide(LlamaForCausalLM):
     def _chain_generate(self, input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter):
         assert input_ids is not None, "please give the input"
         if temperature > 0:
-            raise NotImplementedError("temperature > 0 is a 'next' row (SURVEY 8(f).4)")
+            raise NotImplementedError("chain speculation at temperature > 0 (llama_glide.py:716-736 rejection sampling over "
+                                      "spec_logits) is not implemented: the tree method's verify_stochastic is")
         magic = drafter == "magicdec"
+        self._clear_shard()
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
         dev = input_ids.device
@@ -810,10 +835,12 @@ class LlamaGlide(LlamaForCausalLM):
 def _truncate_after_eos_vanilla(output_ids, num, eos, bsz):
     """The reference tests for EOS after every token and stops (``llama_glide.py:578``); this
     loop tests every 16 tokens to avoid a device sync per token, then restores the reference's
-    visible result: tokens after the first EOS are zero, ``num`` counts forward passes up to it."""
+    visible result: tokens after the first EOS are zero, ``num`` counts forward passes up to it.  Returns
+    (output_ids, num, steps the reference would have run or None)."""
     hit = output_ids.eq(eos)
     if not bool(hit.any()):
-        return output_ids, num
-    first = int(hit.float().argmax(dim=-1).min())
+        return output_ids, num, None
+    # the reference's loop always runs its first step: an EOS as the very first token stops it after step 1 (:571-579)
+    first = max(int(hit.float().argmax(dim=-1).min()), 1)
     output_ids[:, first + 1:] = 0
-    return output_ids, first * bsz
+    return output_ids, first * bsz, first
