@@ -261,6 +261,14 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(base) : "memory", "m0");
 }
 
+// one K and one V piece (4 keys each) of the fast DMA path: wave-uniform 64-bit base, 32-bit per-lane offset
+__device__ __forceinline__ void dma16_s(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform)
+                 : "memory", "m0");
+}
+
 template <typename F>
 __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, int nd, int ngroups, F&& row_ptr) {
     const int kq = lane >> 4, pos = lane & 15;
@@ -842,11 +850,35 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
     const int last_key = L - 1;
 
     // one K piece and one V piece per wave: keys 4*wave .. 4*wave+3 of block b (LDS image swizzled on the source side)
+#ifdef LS_WS_PROF
+    // wall-clock profile of one S wave and one O wave (s_memrealtime: 100 MHz): per-phase sums over the steady steps,
+    // dumped into the (unused, prefix-only call) new_o region by workgroup (split 1, kv head 0) -- tools/ws_prof.py
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pt = 0;
+#define WS_T0() do { pt = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WS_TS(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); prof[i] += n_ - pt; pt = n_; } while (0)
+#else
+#define WS_T0()
+#define WS_TS(i)
+#endif
+    // one K piece and one V piece per wave and block.  Inside the cache (all but the split's last blocks) the source address is
+    // a wave-uniform base (SGPRs) plus ONE per-lane offset register per operand -- the source-side swizzle of a wave's piece
+    // does not depend on the block -- instead of 64-bit per-lane address arithmetic (measured: 106-136 ns of a 1.4 us step)
+    const int kq_ = lane >> 4, pos_ = lane & 15;
+    const unsigned koff_ = (unsigned)(kq_ * kc_row) + ((pos_ ^ (((wave & 3) << 2) | kq_)) << 4);   // key & 15, key = 4*wave + kq_
+    const unsigned voff_ = (unsigned)(kq_ * kc_row) + ((pos_ ^ ((((wave & 1) << 2) | kq_) << 1)) << 4);
     auto dma = [&](int b) {
-        const int key = wave * 4 + (lane >> 4), pos = lane & 15;
-        const long ka = min((b_begin + b) * 32 + key, last_key);        // tail rows: re-read the last valid key (masked)
-        dma16(kc_base + ka * kc_row + ((pos ^ (key & 15)) << 4), smem + (b % WS_NK) * WS_BLK_B + wave * 1024);
-        dma16(vc_base + ka * kc_row + ((pos ^ ((key & 7) << 1)) << 4), smem + (WS_NK + b % WS_NV) * WS_BLK_B + wave * 1024);
+        const int bg = b_begin + b;
+        if (bg * 32 + 32 <= L) {
+            const long row = ((long)bg * 32 + wave * 4) * kc_row;
+            dma16_s(kc_base + row, koff_, smem_a + (b % WS_NK) * WS_BLK_B + wave * 1024);
+            dma16_s(vc_base + row, voff_, smem_a + (WS_NK + b % WS_NV) * WS_BLK_B + wave * 1024);
+        } else {
+            const int key = wave * 4 + kq_;
+            const long ka = min(bg * 32 + key, last_key);                   // tail rows: re-read the last valid key (masked)
+            dma16(kc_base + ka * kc_row + ((pos_ ^ (key & 15)) << 4), smem + (b % WS_NK) * WS_BLK_B + wave * 1024);
+            dma16(vc_base + ka * kc_row + ((pos_ ^ ((key & 7) << 1)) << 4), smem + (WS_NK + b % WS_NV) * WS_BLK_B + wave * 1024);
+        }
     };
     auto k_addr = [&](int b) -> unsigned { return smem_a + (b % WS_NK) * WS_BLK_B; };
     auto v_addr = [&](int b) -> unsigned { return smem_a + (WS_NK + b % WS_NV) * WS_BLK_B; };
@@ -962,8 +994,10 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             } else {
                 // steady state: ONE basic block holds the QK^T MFMAs of block j+1 and the VALU work of block j, so that
                 // the scheduler can lay them out as asked below: an MFMA, then the VALU instructions its 16 cycles hide
-                auto steady_step = [&](int j, auto masked) {
+                auto steady_step = [&](int j, auto masked, auto fixed_wait) {
+                    WS_T0();
                     step_head(j);
+                    WS_TS(0);
                     f32x4 s_next[2][QT];
                     qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
                     softmax_store(j);
@@ -979,13 +1013,26 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) s_cur[kt][qt] = s_next[kt][qt];
-                    step_tail(j);
+                    WS_TS(1);
+                    // K(j+2) is multiplied at step j+1.  In the steady state exactly LA-1 younger blocks (2 pieces each) are in
+                    // flight: one immediate wait instead of the compare / branch ladder of wait_block (measured: 155-170 ns of
+                    // a 1.4 us step went into that ladder)
+                    if constexpr (decltype(fixed_wait)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1)) : "memory");
+                    else wait_block(j + 2, min(nblocks, j + 2 + WS_LA));
+                    WS_TS(2);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    WS_TS(3);
+                    __builtin_amdgcn_s_barrier();
+                    WS_TS(4);
                 };
                 // only the split's LAST block can cross the end of the cache: its masking (35 selects per lane when the
                 // compiler if-converts it into every iteration) is peeled off the loop
+                const int n_fixed = max(0, nblocks - 1 - WS_LA);      // steps j with j + 2 + LA <= nblocks
 #pragma unroll 1
-                for (int j = 0; j + 2 < nblocks; ++j) steady_step(j, std::false_type{});
-                if (nblocks > 1) steady_step(nblocks - 2, std::true_type{});
+                for (int j = 0; j < n_fixed; ++j) steady_step(j, std::false_type{}, std::true_type{});
+#pragma unroll 1
+                for (int j = n_fixed; j + 2 < nblocks; ++j) steady_step(j, std::false_type{}, std::false_type{});
+                if (nblocks > 1) steady_step(nblocks - 2, std::true_type{}, std::false_type{});
                 if (nblocks > 0) {                         // last block: nothing left to multiply
                     step_head(nblocks - 1);
                     softmax_store(nblocks - 1);
@@ -1006,6 +1053,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             run_pass(1);
             run_pass(2);
         }
+#ifdef LS_WS_PROF
+        if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && wave == 0 && lane < 6)
+            reinterpret_cast<unsigned long long*>(p.new_o)[lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
+                                                                   prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
+#endif
         // row sums and the log-normaliser; the O wave of the pair scales its accumulators by 1/l
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -1033,7 +1085,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             __builtin_amdgcn_s_barrier();          // the S waves' look at blocks 0 and 1 is over
 #pragma unroll 1
             for (int j = 0; j <= nblocks; ++j) {
+                WS_T0();
                 step_head(j);
+                WS_TS(0);
                 if (mode != 1 && j >= 1) {
                     const int jj = j - 1;
                     typename E::V8 pf[QT];
@@ -1058,7 +1112,15 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
                 }
-                step_tail(j);
+                WS_TS(1);
+                // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
+                if (j + 2 + WS_LA <= nblocks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1)) : "memory");
+                else wait_block(j + 2, min(nblocks, j + 2 + WS_LA));
+                WS_TS(2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                WS_TS(3);
+                __builtin_amdgcn_s_barrier();
+                WS_TS(4);
             }
         };
         run_pass(0);
@@ -1069,6 +1131,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             run_pass(1);
             run_pass(2);
         }
+#ifdef LS_WS_PROF
+        if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && wave == 4 && lane < 6)
+            reinterpret_cast<unsigned long long*>(p.new_o)[8 + lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
+                                                                       prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
+#endif
         __syncthreads();                           // the pair's 1/l is in LDS
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -1236,13 +1303,6 @@ struct V2 {
     }
 };
 
-// one K and one V piece (4 keys each) of the fast DMA path: wave-uniform 64-bit base, 32-bit per-lane offset
-__device__ __forceinline__ void dma16_s(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform)
-                 : "memory", "m0");
-}
 
 #ifndef V2_STAMP_WAVE
 #define V2_STAMP_WAVE 0
