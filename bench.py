@@ -10,8 +10,8 @@ draft passes growing the 69-node beam tree, one 74-row target pass through all 3
 hybrid tree-verification attention, accept/collapse.  Default workload = the configuration BASELINE.json's
 metric is quoted on: Llama-3-8B-Instruct-262k dimensions + longspec draft layer, **131072-token** synthetic
 prefix, fp16, temperature 0 -- it fits one GPU (16 GiB of KV).  ``--gpus N`` splits that FIXED prefix N ways
-by sequence (strong scaling; 16k rows per GPU at N = 8 = configs[2]); partial attention outputs are merged
-with one RCCL all-gather per attention call (longspec_amd/dist.py).  ``--prefix-per-gpu R`` is the secondary
+by sequence (strong scaling; 16k rows per GPU at N = 8 = configs[2]); partial attention outputs travel rank to
+rank through IPC-mapped mailboxes (csrc/xgmi.hip; --exchange collective = one RCCL all-gather per call instead).  ``--prefix-per-gpu R`` is the secondary
 weak-scaling mode (R rows on every GPU; ``--prefix-per-gpu 16384`` at N = 1 is configs[1]).
 
 Synthetic data: random-init weights of the named architecture made "mixed-agreement" (o_proj and
@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="diagnostic: gloo lets several ranks share ONE GPU (with --share-gpu) to exercise the N > 1 code path")
+    ap.add_argument("--exchange", default="peer", choices=["peer", "collective"],
+                    help="N > 1: how the per-rank attention records travel -- peer stores into IPC mailboxes (graph-capturable, "
+                         "default) or one torch.distributed all-gather per attention call")
     ap.add_argument("--share-gpu", action="store_true", help="diagnostic: every rank uses cuda:0")
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
@@ -341,6 +344,10 @@ def main():
         for layer in m.model.layers:
             layer.self_attn.shard = shard
         m.glide.cross_attn.shard = shard
+        if args.exchange == "peer":
+            # records go rank to rank through IPC-mapped mailboxes (csrc/xgmi.hip): the round stays a HIP graph.  Falls
+            # back to the library collective (and says so) when the mapping or its self-check fails.
+            shard.enable_peer_exchange(128 * max(H, m.glide.config.num_attention_heads) * 129, device)
 
     lens = torch.tensor([L_total], dtype=torch.int32, device=device)
     first = torch.tensor([1000], dtype=torch.int64, device=device)
@@ -405,6 +412,12 @@ def main():
         "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
         "hip_graphs": bool(graphs and st.graphs is not False),
     }
+    if world > 1 or args.shard_path:
+        out["exchange"] = ("peer stores into IPC-mapped mailboxes (csrc/xgmi.hip), 2 launches per attention call" if shard.peer is not None
+                           else "torch.distributed all-gather per attention call")
+        if shard.peer is not None:
+            done, timed_out = shard.peer.status()
+            out["exchange_calls"], out["exchange_timed_out"] = done, timed_out
 
     if rank == 0:
         # ---- roofline of the kernel north_star names: the hybrid verification attention, stage 1 (this rank's KV shard).
@@ -472,11 +485,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, Ls, args.cpu_sample_calls, tau)
             if not args.no_cpu_round:
                 out["cpu_baseline_round"] = cpu_baseline_round(TREE)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1 or args.shard_path:
+        if shard.peer is not None:
+            shard.peer.close()
         dist.barrier()
         dist.destroy_process_group()
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: push it out now so that the
+        # JSON line below is the LAST line of rank 0's stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -307,6 +307,32 @@ int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int
 int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int n,
                   void* out, void* stream);
 
+/* ---- multi-GPU: peer exchange of the per-rank attention records -----------------
+ * Replaces the one all-gather per attention call of a sequence-sharded prefix (the reference has no counterpart:
+ * `device_map="auto"`, llama_glide.py:474) by peer stores into IPC-mapped mailboxes + flags, so that a decode round
+ * containing it is pure kernel launches and replays from a HIP graph.  One object per process (= per GPU).
+ *   create  -> handle (64 bytes, exchanged between the ranks by the host: torch.distributed, a pipe, ...)
+ *           -> connect (all `world` handles in rank order; opens the peers' mailboxes)
+ *           -> all_gather any number of times; every rank issues the same sequence of calls
+ *   all_gather: gathered[r*stride_floats .. +n_floats) = rank r's `record` (n_floats <= cap_floats, multiples of 4,
+ *   16-byte aligned).  Two launches on `stream`, no host synchronisation.  A peer that never delivers makes the
+ *   wait give up after seconds and latches `timed_out` (ls_xchg_status; the gathered data is then invalid). */
+#define LS_XCHG_MAX_WORLD 16
+#define LS_XCHG_HANDLE_BYTES 64
+typedef struct ls_xchg ls_xchg;
+int ls_xchg_create(int rank, int world, size_t cap_floats, ls_xchg** out);
+int ls_xchg_handle(ls_xchg* x, void* handle /* LS_XCHG_HANDLE_BYTES */);
+int ls_xchg_connect(ls_xchg* x, const void* handles /* world * LS_XCHG_HANDLE_BYTES, rank order */);
+int ls_xchg_all_gather(ls_xchg* x, const float* record, size_t n_floats, float* gathered, size_t stride_floats, void* stream);
+int ls_xchg_status(ls_xchg* x, uint64_t* epoch, int* timed_out); /* synchronising; diagnostics only */
+/* The same exchange fused into the two combine kernels of a sharded attention call: ls_attn_reduce_push =
+ * ls_attn_reduce_local whose record goes straight into the peers' mailboxes (+ flags); ls_attn_finish_xchg =
+ * ls_attn_finish over the mailbox slots of this exchange, read once every rank's flag is up.  One exchange =
+ * one reduce_push followed by one finish_xchg on every rank (3 launches per attention call, 2 without a shard). */
+int ls_attn_reduce_push(const ls_attn_desc* d, void* workspace, size_t workspace_bytes, ls_xchg* x, void* stream);
+int ls_attn_finish_xchg(const ls_attn_desc* d, ls_xchg* x, void* workspace, size_t workspace_bytes, void* stream);
+int ls_xchg_destroy(ls_xchg* x);
+
 #ifdef __cplusplus
 }
 #endif

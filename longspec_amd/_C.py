@@ -88,6 +88,14 @@ SYMBOLS = {
     "ls_tree_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _I, _P, _I, _L, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "ls_embed_rows": (C.c_int, [_P, _L, _I, _I, _P, _I, _P, _P]),
     "ls_chain_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _P, _P, _P, _P, _I, _L, _P, _P]),
+    "ls_xchg_create": (C.c_int, [_I, _I, C.c_size_t, C.POINTER(_P)]),
+    "ls_xchg_handle": (C.c_int, [_P, _P]),
+    "ls_xchg_connect": (C.c_int, [_P, _P]),
+    "ls_xchg_all_gather": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "ls_xchg_status": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(_I)]),
+    "ls_xchg_destroy": (C.c_int, [_P]),
+    "ls_attn_reduce_push": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P]),
+    "ls_attn_finish_xchg": (C.c_int, [C.POINTER(AttnDesc), _P, _P, C.c_size_t, _P]),
 }
 
 

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "liblongspec_hip.so")
-SOURCES = ["attn.hip", "gemm.hip", "misc.hip", "topk.hip", "tree.hip"]
+SOURCES = ["attn.hip", "gemm.hip", "misc.hip", "topk.hip", "tree.hip", "xgmi.hip"]
 HEADERS = [os.path.join(CSRC, "ls_common.h"), os.path.join(os.path.dirname(HERE), "include", "longspec_hip.h")]
 # -ffp-contract=off: the reference-order roundings (fp16 product, fp16 sum) must not be fused into FMAs
 # -Wno-inline-asm: the LDS-DMA helper names m0 in its clobber list on purpose.  -Wno-division-by-zero: the HOST pass folds

@@ -1994,17 +1994,42 @@ struct FinK {
     int n_parts, b, sq, H, mode;   // mode = LS_NEW_*
     long part_o_stride, part_lse_stride;   // elements between consecutive parts
     long out_sb, out_ss, out_sh;
+    // sequence-sharded prefix (xgmi.hip): x_mode 1 = the (o32, lse) record goes into slot [parity][rank] of every peer's
+    // mailbox, a flag follows it and the epoch moves on; 2 = the parts ARE the mailbox slots [parity][0..world) of this
+    // rank, read once every peer's flag of the epoch just pushed is up
+    int x_mode, x_rank, x_world;
+    long x_cap, x_lse_off;                 // floats per slot; offset of the lse block inside a record
+    char* const* x_peers;
+    const char* x_box;
+    XCtl* x_ctl;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <typename E>
+template <typename E, int XM>                      // XM = FinK::x_mode, a compile-time copy (0: no exchange code at all)
 __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     const int tid = threadIdx.x;
-    const int r = blockIdx.x * 8 + (tid >> 5);
+    const int r_ = blockIdx.x * 8 + (tid >> 5);
+    const bool act = r_ < p.sq;                    // rows of the last block beyond sq: no stores
+    if (!act && XM == 0) return;
+    const int r = act ? r_ : p.sq - 1;             // (exchange modes: every thread stays for the barriers)
     const int h = blockIdx.y, bi = blockIdx.z;
     const int d = (tid & 31) * 4;
-    if (r >= p.sq) return;
+    const float* parts_o_ = p.parts_o;
+    const float* parts_lse_ = p.parts_lse;
+    unsigned long long epoch = 0;
+    int parity = 0;
+    if constexpr (XM != 0) {                       // (no thread has left yet)
+        epoch = p.x_ctl->epoch - (XM == 2 ? 1 : 0);        // (the push in front of a wait has moved it on)
+        parity = (int)(epoch & 1);
+        if constexpr (XM == 2) {
+            if (tid < p.x_world) xchg_wait_flag(p.x_box, p.x_ctl, parity, tid, epoch);
+            __syncthreads();
+            parts_o_ = reinterpret_cast<const float*>(p.x_box + XCHG_DATA_OFF) + (long)parity * p.x_world * p.x_cap;
+            parts_lse_ = parts_o_ + p.x_lse_off;
+            if (!act) return;                      // (behind the barrier)
+        }
+    }
     const long lse_idx = ((long)bi * p.H + h) * p.sq + r;
     const long o_idx = (((long)bi * p.sq + r) * p.H + h) * D + d;
     const long part_lse_stride = p.part_lse_stride;
@@ -2021,15 +2046,15 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         // so the number of dependent load batches is its run time.  Parts beyond n re-read part n-1 with weight 0.
         float l[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) l[u] = p.parts_lse[(u < n ? u : n - 1) * part_lse_stride + lse_idx];
+        for (int u = 0; u < 32; ++u) l[u] = parts_lse_[(u < n ? u : n - 1) * part_lse_stride + lse_idx];
         f32x4 oa[16], ob[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            oa[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (u < n ? u : n - 1) * part_o_stride + o_idx);
+            oa[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (u < n ? u : n - 1) * part_o_stride + o_idx);
         if (n > 16) {
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                ob[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (16 + u < n ? 16 + u : n - 1) * part_o_stride + o_idx);
+                ob[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (16 + u < n ? 16 + u : n - 1) * part_o_stride + o_idx);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -2054,7 +2079,7 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         // pass 1: reference max over the parts (independent scalar loads)
         float mx = -INFINITY;
 #pragma unroll 8
-        for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, p.parts_lse[i * part_lse_stride + lse_idx]);
+        for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, parts_lse_[i * part_lse_stride + lse_idx]);
         if (joint) mx = fmaxf(mx, lnew);
         mref = mx == -INFINITY ? 0.f : mx;
         // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
@@ -2065,8 +2090,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             f32x4 o8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                l8[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
-                o8[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+                l8[u] = parts_lse_[(i + u) * part_lse_stride + lse_idx];
+                o8[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (i + u) * part_o_stride + o_idx);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -2080,8 +2105,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             f32x4 o4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                l4[u] = p.parts_lse[(i + u) * part_lse_stride + lse_idx];
-                o4[u] = *reinterpret_cast<const f32x4*>(p.parts_o + (i + u) * part_o_stride + o_idx);
+                l4[u] = parts_lse_[(i + u) * part_lse_stride + lse_idx];
+                o4[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (i + u) * part_o_stride + o_idx);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2091,9 +2116,9 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             }
         }
         for (; i < p.n_parts; ++i) {
-            const float wgt = expf(p.parts_lse[i * part_lse_stride + lse_idx] - mref);
+            const float wgt = expf(parts_lse_[i * part_lse_stride + lse_idx] - mref);
             den += wgt;
-            o += *reinterpret_cast<const f32x4*>(p.parts_o + i * part_o_stride + o_idx) * wgt;
+            o += *reinterpret_cast<const f32x4*>(parts_o_ + i * part_o_stride + o_idx) * wgt;
         }
     }
     if (joint && lnew != -INFINITY) {
@@ -2106,10 +2131,32 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         o = o / den;
         lse = mref + logf(den);
     }
-    if (p.o32) *reinterpret_cast<f32x4*>(p.o32 + o_idx) = o;
+    if (p.o32 && act) *reinterpret_cast<f32x4*>(p.o32 + o_idx) = o;
     // LS_NEW_DRAFT: the log-normaliser asked for is the tree kernel's L (triton_tree_attn.attention returns (o, L))
-    if (p.lse_out && (tid & 31) == 0) p.lse_out[lse_idx] = (p.mode == LS_NEW_DRAFT) ? lnew : lse;
-    if (!p.out) return;
+    if (p.lse_out && act && (tid & 31) == 0) p.lse_out[lse_idx] = (p.mode == LS_NEW_DRAFT) ? lnew : lse;
+    if (XM == 1 && act) {
+        // this rank's record, straight into every peer's mailbox (its own included): peer stores over xGMI
+        const long slot = ((long)parity * p.x_world + p.x_rank) * p.x_cap;
+        for (int dst = 0; dst < p.x_world; ++dst) {
+            float* rec = reinterpret_cast<float*>(p.x_peers[dst] + XCHG_DATA_OFF) + slot;
+            xchg_store16(rec + o_idx, o);
+            if ((tid & 31) == 0) xchg_store4(rec + p.x_lse_off + lse_idx, lse);
+        }
+        xchg_stores_done();                        // acknowledged by every peer before this workgroup counts itself in
+    }
+    if constexpr (XM == 1) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int* ctr = &p.x_ctl->arrive_all;
+            const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x * gridDim.y * gridDim.z - 1) {       // the whole record has landed everywhere: raise the flags
+                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int dst = 0; dst < p.x_world; ++dst) xchg_raise_flag(p.x_peers[dst], parity, p.x_rank, epoch);
+                __hip_atomic_store(&p.x_ctl->epoch, epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (!p.out || !act) return;
 
     float res[4];
     if (p.mode == LS_NEW_TARGET) {
@@ -2402,8 +2449,16 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
 
 int run_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_lse, int n_parts, const float* new_o,
                const float* new_lse, int mode, void* out, float* o32, float* lse, hipStream_t s, long part_o_stride = 0,
-               long part_lse_stride = 0) {
+               long part_lse_stride = 0, const ls_xchg* x = nullptr, int x_mode = 0) {
     FinK f;
+    f.x_mode = x ? x_mode : 0;
+    f.x_rank = x ? x->rank : 0;
+    f.x_world = x ? x->world : 0;
+    f.x_cap = x ? (long)x->cap_floats : 0;
+    f.x_lse_off = (long)d->b * d->sq * d->H * D;
+    f.x_peers = x ? x->peers_dev : nullptr;
+    f.x_box = x ? x->box : nullptr;
+    f.x_ctl = x ? x->ctl : nullptr;
     f.part_o_stride = part_o_stride ? part_o_stride : (long)d->b * d->sq * d->H * D;
     f.part_lse_stride = part_lse_stride ? part_lse_stride : (long)d->b * d->H * d->sq;
     f.parts_o = parts_o;
@@ -2418,10 +2473,16 @@ int run_finish(const ls_attn_desc* d, const float* parts_o, const float* parts_l
     f.mode = mode;
     f.out_sb = d->out_stride_b; f.out_ss = d->out_stride_s; f.out_sh = d->out_stride_h;
     dim3 grid((d->sq + 7) / 8, d->H, d->b);
-    if (d->dtype == LS_F16)
-        hipLaunchKernelGGL(attn_finish_kernel<ElemF16>, grid, dim3(256), 0, s, f);
-    else
-        hipLaunchKernelGGL(attn_finish_kernel<ElemBF16>, grid, dim3(256), 0, s, f);
+    auto launch = [&](auto xm) {
+        constexpr int XM = decltype(xm)::value;
+        if (d->dtype == LS_F16)
+            hipLaunchKernelGGL((attn_finish_kernel<ElemF16, XM>), grid, dim3(256), 0, s, f);
+        else
+            hipLaunchKernelGGL((attn_finish_kernel<ElemBF16, XM>), grid, dim3(256), 0, s, f);
+    };
+    if (f.x_mode == 1) launch(std::integral_constant<int, 1>{});
+    else if (f.x_mode == 2) launch(std::integral_constant<int, 2>{});
+    else launch(std::integral_constant<int, 0>{});
     LS_CHECK_LAUNCH("attn_finish_kernel");
     return LS_OK;
 }
@@ -2489,6 +2550,39 @@ int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* par
     return run_finish(d, parts_o, parts_lse, n_parts, has_new ? reinterpret_cast<float*>(base + w.new_o) : nullptr,
                       has_new ? reinterpret_cast<float*>(base + w.new_lse) : nullptr, d->new_mode, d->out, nullptr,
                       d->lse, static_cast<hipStream_t>(stream), (long)part_o_stride, (long)part_lse_stride);
+}
+
+static int xchg_fits(const ls_attn_desc* d, const ls_xchg* x) {
+    if (!x || !x->connected) LS_FAIL(LS_ERR_INVALID_ARG, "exchange object null or not connected");
+    const size_t rec = (size_t)d->b * d->sq * d->H * (D + 1);
+    if (rec > x->cap_floats) LS_FAIL(LS_ERR_INVALID_ARG, "record of %zu floats exceeds the mailbox slot (%zu)", rec, x->cap_floats);
+    return LS_OK;
+}
+
+int ls_attn_reduce_push(const ls_attn_desc* d, void* ws, size_t ws_bytes, ls_xchg* x, void* stream) {
+    if (validate(d)) return LS_ERR_INVALID_ARG;
+    if (xchg_fits(d, x)) return LS_ERR_INVALID_ARG;
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const WsLayout w = ws_layout(d, c, pick_splits(d, c));
+    if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
+    char* base = static_cast<char*>(ws);
+    return run_finish(d, reinterpret_cast<float*>(base + w.parts_o), reinterpret_cast<float*>(base + w.parts_lse), w.n_parts, nullptr,
+                      nullptr, LS_NEW_NONE, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream), 0, 0, x, 1);
+}
+
+int ls_attn_finish_xchg(const ls_attn_desc* d, ls_xchg* x, void* ws, size_t ws_bytes, void* stream) {
+    if (validate(d)) return LS_ERR_INVALID_ARG;
+    if (!d->out) LS_FAIL(LS_ERR_INVALID_ARG, "out null");
+    if (xchg_fits(d, x)) return LS_ERR_INVALID_ARG;
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const WsLayout w = ws_layout(d, c, pick_splits(d, c));
+    const bool has_new = d->new_mode != LS_NEW_NONE;
+    if (has_new && (!ws || ws_bytes < w.total)) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
+    char* base = static_cast<char*>(ws);
+    // parts = the mailbox slots of this epoch (resolved on the device); stride = one slot
+    return run_finish(d, nullptr, nullptr, x->world, has_new ? reinterpret_cast<float*>(base + w.new_o) : nullptr,
+                      has_new ? reinterpret_cast<float*>(base + w.new_lse) : nullptr, d->new_mode, d->out, nullptr, d->lse,
+                      static_cast<hipStream_t>(stream), (long)x->cap_floats, (long)x->cap_floats, x, 2);
 }
 
 int ls_lse_merge(const float* parts_o, const float* parts_lse, int n_parts, int b, int sq, int H, int dtype, void* out,

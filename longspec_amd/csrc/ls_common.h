@@ -67,3 +67,54 @@ __device__ __forceinline__ float wave_xor_sum_16_32(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
+
+// ---- peer exchange (xgmi.hip; attn.hip fuses it into the reduce / finish kernels of a sharded attention call) ----
+constexpr int XCHG_MAX_WORLD = LS_XCHG_MAX_WORLD;
+constexpr size_t XCHG_DATA_OFF = 256;             // flags: u64 [2][16] = 256 bytes, then f32 [2][world][cap_floats]
+constexpr unsigned XCHG_SPIN_LIMIT = 4u << 20;    // x s_sleep(32): seconds, not forever -- a dead peer must not hang the GPU
+
+struct XCtl {
+    unsigned long long epoch;                      // the NEXT exchange to push; counted on the device (graph replays advance it):
+                                                   // a push reads e and leaves e + 1, the wait behind it works on epoch - 1
+    unsigned int error;                            // latched: a wait gave up
+    unsigned int arrive_all;
+    unsigned int arrive_push[XCHG_MAX_WORLD];
+};
+
+struct ls_xchg {
+    int rank, world;
+    size_t cap_floats, box_bytes;
+    char* box;                                     // local mailbox
+    XCtl* ctl;
+    char** peers_dev;                              // device array [world] of mailbox addresses as this process maps them
+    char* peers[XCHG_MAX_WORLD];
+    bool connected;
+};
+
+// Stores into a mailbox (local or a peer's): write-through at system scope (sc0 sc1), so that "all my stores are
+// acknowledged" is s_waitcnt vmcnt(0) and not a release fence -- a system-scope release writes the whole L2 back
+// (the split partials of the attention call are still dirty in it: measured +35 us per call with fences).
+__device__ __forceinline__ void xchg_store16(void* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void xchg_store4(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void xchg_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void xchg_raise_flag(char* box, int parity, int rank, unsigned long long epoch) {
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(box) + parity * XCHG_MAX_WORLD + rank;
+    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (ordered behind the data by the waits above)
+}
+
+// poll flag[parity][src] of the local mailbox until rank `src` has delivered epoch `epoch` (one thread per source)
+__device__ __forceinline__ void xchg_wait_flag(const char* box, XCtl* ctl, int parity, int src, unsigned long long epoch) {
+    const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(box) + parity * XCHG_MAX_WORLD + src;
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > XCHG_SPIN_LIMIT) {
+            __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}

@@ -13,6 +13,10 @@ Per attention call each rank streams only its slice and produces one normalised 
 all-gather (each of the 7 xGMI links carries 1/7 of the traffic in a single step -- a ring
 all-reduce would be 14 dependent per-link steps for this latency-bound message) and merged by
 every rank in rank order, so the result is bit-identical on all ranks and independent of timing.
+On GPUs the all-gather is ``PeerExchange``: every rank stores its record into IPC-mapped mailboxes in
+its peers' HBM and raises a flag (``csrc/xgmi.hip``) -- two kernel launches, so that the decode round
+stays capturable in a HIP graph; the ``torch.distributed`` collective remains for the CPU tests, for
+records larger than a mailbox slot (prefill) and as the fallback when the self-check fails.
 The reference has no counterpart (``device_map="auto"`` only, ``llama_glide.py:474``); the merge
 is the N-way form of its 2-way ``o_p*sigmoid(lse_p-lse_t) + o_t*(1-sigmoid)`` (``llama.py:385-387,420``).
 """
@@ -20,8 +24,75 @@ from __future__ import annotations
 
 from typing import Optional
 
+import ctypes as C
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+class PeerExchange:
+    """All-gather of one fp32 record per rank through IPC-mapped mailboxes (``include/longspec_hip.h``: ``ls_xchg_*``).
+    Construction is collective over ``group``: the 64-byte IPC handles travel by ``torch.distributed``."""
+
+    def __init__(self, rank: int, world: int, cap_floats: int, device, group=None):
+        from . import _C
+        self._C, self.lib = _C, _C.load()
+        self.rank, self.world, self.group, self.device = rank, world, group, device
+        self.cap = (int(cap_floats) + 3) // 4 * 4
+        self._x = C.c_void_p()
+        with torch.cuda.device(device):
+            _C.check(self.lib.ls_xchg_create(rank, world, self.cap, C.byref(self._x)), "ls_xchg_create")
+            h = (C.c_ubyte * 64)()
+            _C.check(self.lib.ls_xchg_handle(self._x, h), "ls_xchg_handle")
+            on = device if dist.get_backend(group) == "nccl" else "cpu"
+            mine = torch.tensor(list(bytes(h)), dtype=torch.uint8, device=on)
+            every = torch.empty(world * 64, dtype=torch.uint8, device=on)
+            dist.all_gather_into_tensor(every, mine, group=group)
+            _C.check(self.lib.ls_xchg_connect(self._x, bytes(every.cpu().tolist())), "ls_xchg_connect")
+        dist.barrier(group=group)                  # nobody pushes before every mailbox is mapped
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
+        """recv [world, stride] <- every rank's ``send`` (fp32, numel a multiple of 4, <= cap).  Current stream, no host sync."""
+        assert send.dtype == recv.dtype == torch.float32 and send.is_contiguous() and recv.stride(1) == 1
+        self._C.check(self.lib.ls_xchg_all_gather(self._x, send.data_ptr(), send.numel(), recv.data_ptr(), recv.stride(0),
+                                                  torch.cuda.current_stream(send.device).cuda_stream), "ls_xchg_all_gather")
+        return recv
+
+    def status(self):
+        """(exchanges completed, timed_out) -- synchronises the device."""
+        epoch, bad = C.c_uint64(0), C.c_int(0)
+        with torch.cuda.device(self.device):
+            self._C.check(self.lib.ls_xchg_status(self._x, C.byref(epoch), C.byref(bad)), "ls_xchg_status")
+        return int(epoch.value) - 1, bool(bad.value)
+
+    def self_check(self, rounds: int = 3, n: int = 4096) -> bool:
+        """A few exchanges of rank-dependent patterns compared with the library collective; every rank gets the same verdict."""
+        ok = True
+        n = min(n, self.cap)
+        for i in range(rounds):
+            send = (torch.arange(n, dtype=torch.float32, device=self.device) * (self.rank + 1) + i).contiguous()
+            got = torch.zeros((self.world, n), dtype=torch.float32, device=self.device)
+            ref = torch.zeros_like(got)
+            self.all_gather(send, got)
+            dist.all_gather_into_tensor(ref.view(-1), send, group=self.group)
+            ok = ok and bool(torch.equal(got, ref))
+        ok = ok and not self.status()[1]
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def close(self):
+        if self._x:
+            with torch.cuda.device(self.device):
+                self.lib.ls_xchg_destroy(self._x)
+            self._x = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class KVShard:
@@ -33,6 +104,36 @@ class KVShard:
         self._recv = {}
         self._pass_len = {}
         self.prefill_ctx = None          # (first global row, local rows, prompt rows) while a sharded prefill runs
+        self.peer: Optional[PeerExchange] = None     # set by enable_peer_exchange: the graph-capturable exchange
+        self.peer_tried = False
+
+    # ---- the graph-capturable exchange ----------------------------------------------------------
+    def enable_peer_exchange(self, cap_floats: int, device) -> bool:
+        """Collective: map the peers' mailboxes and verify a few exchanges against the library collective.  On any
+        failure the shard stays on the ``torch.distributed`` all-gather (and says so on stderr) -- never silently."""
+        if self.peer is not None and self.peer.cap >= cap_floats:
+            return True
+        self.peer_tried = True
+        if self.peer is not None:
+            self.peer.close()
+            self.peer = None
+        try:
+            peer = PeerExchange(self.rank, self.world, cap_floats, device, self.group)
+            if peer.self_check():
+                self.peer = peer
+            else:
+                peer.close()
+                print(f"[longspec_amd.dist] rank {self.rank}: peer-store exchange failed its self-check; "
+                      "using the torch.distributed all-gather", file=sys.stderr, flush=True)
+        except Exception as e:                      # noqa: BLE001 -- IPC not available on this system
+            print(f"[longspec_amd.dist] rank {self.rank}: peer-store exchange unavailable ({e}); "
+                  "using the torch.distributed all-gather", file=sys.stderr, flush=True)
+        return self.peer is not None
+
+    @property
+    def graph_safe(self) -> bool:
+        """A decode round under this shard is pure kernel launches."""
+        return self.peer is not None
 
     # ---- lengths ---------------------------------------------------------------------------------
     def local_len(self, global_len: torch.Tensor) -> torch.Tensor:
@@ -60,9 +161,10 @@ class KVShard:
 
     # ---- the one collective of the data path ---------------------------------------------------
     def buffers(self, n_floats: int, device):
+        n_floats = (n_floats + 3) // 4 * 4          # the peer exchange moves 16-byte units
         key = (n_floats, str(device))
         if key not in self._send:
-            self._send[key] = torch.empty(n_floats, dtype=torch.float32, device=device)
+            self._send[key] = torch.zeros(n_floats, dtype=torch.float32, device=device)
             self._recv[key] = torch.empty((self.world, n_floats), dtype=torch.float32, device=device)
         return self._send[key], self._recv[key]
 
@@ -80,11 +182,15 @@ class KVShard:
         return t
 
     def exchange(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
+        if self.peer is not None and send.numel() <= self.peer.cap:
+            return self.peer.all_gather(send, recv)
         dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
         return recv
 
     def attend(self, call) -> torch.Tensor:
         """partial -> all-gather -> merge, for one ``ShardedAttnCall``-like object."""
+        if self.peer is not None and call.record_floats <= self.peer.cap and hasattr(call, "attend_peer"):
+            return call.attend_peer(self.peer._x)
         send, recv = self.buffers(call.record_floats, call.device)
         call.partial(send)
         return call.finish(self.exchange(send, recv))

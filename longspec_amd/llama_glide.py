@@ -488,6 +488,10 @@ class LlamaGlide(LlamaForCausalLM):
             layer.self_attn.shard = shard
         self.glide.cross_attn.shard = shard
         if shard is not None:
+            if dev.type == "cuda" and not shard.peer_tried:
+                # a mailbox slot holds the record of the widest pass: 128 rows x heads x (128 + 1) floats
+                heads = max(self.config.num_attention_heads, self.glide.config.num_attention_heads)
+                shard.enable_peer_exchange(bsz * 128 * heads * 129, dev)
             first = self._sharded_prefill(input_ids, input_len, position_ids, shard)
         else:
             # prefill LLM (:954-960)
@@ -572,9 +576,10 @@ class LlamaGlide(LlamaForCausalLM):
         st.a = 1                              # host mirror of acc_num (G9: the pad id is outside the vocab)
         st.emitted = 1                        # tokens written to output_ids so far (host mirror of emitted_dev)
         st.emitted_dev = torch.ones((bsz,), dtype=torch.int32, device=dev)
-        # HIP graphs of the round, one per `a`: on a GPU, without a KV shard (a collective inside a captured round is
-        # not something this build could test) -- callers that bracket kernels with events switch it off per round
-        st.use_graphs = bool(dev.type == "cuda" and self.model.layers[-1].self_attn.shard is None and self.GRAPH_ROUNDS)
+        # HIP graphs of the round, one per `a`: on a GPU; under a KV shard only when its exchange is the peer-store one
+        # (kernel launches only: dist.PeerExchange) -- callers that bracket kernels with events switch it off per round
+        sh = self.model.layers[-1].self_attn.shard
+        st.use_graphs = bool(dev.type == "cuda" and (sh is None or sh.graph_safe) and self.GRAPH_ROUNDS)
         st.graphs, st.graph_stream, st.graph_pool, st.graphs_forced = {}, None, None, False
         st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
         st.tree_mask[:, :, 0] = 1

@@ -588,6 +588,17 @@ class ShardedAttnCall:
                                           sendbuf.data_ptr() + 4 * self.n_o, _stream()), "ls_attn_reduce_local")
         return sendbuf
 
+    def attend_peer(self, xchg) -> torch.Tensor:
+        """partial -> reduce + peer stores -> wait + merge: the exchange rides inside the two combine kernels
+        (``xchg`` = the ``ls_xchg*`` of ``dist.PeerExchange``).  Kernel launches only: graph-capturable."""
+        lib = _C.load()
+        d = self.d
+        ws, n, st = self.ws.data_ptr(), self.ws.numel(), _stream()
+        _C.check(lib.ls_attn_partial(C.byref(d), ws, n, st), "ls_attn_partial")
+        _C.check(lib.ls_attn_reduce_push(C.byref(d), ws, n, xchg, st), "ls_attn_reduce_push")
+        _C.check(lib.ls_attn_finish_xchg(C.byref(d), xchg, ws, n, st), "ls_attn_finish_xchg")
+        return self.out
+
     def finish(self, gathered: torch.Tensor) -> torch.Tensor:
         """gathered: fp32 [W, record_floats] (row w = rank w's record)."""
         lib = _C.load()

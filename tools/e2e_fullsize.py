@@ -90,14 +90,15 @@ def main():
         return {"pos": k, "vanilla": int(v_out[0, k]), name: int(out[0, k]),
                 "teacher_forced_top3": top.indices[k].tolist(), "top3_logits": [round(x, 4) for x in top.values[k].tolist()],
                 "margin": round(float(margin[k]), 5), "margin_ulps": round(float(margin_ulps[k]), 2),
-                "margin_rank_among_positions": rank, "other_is_top2": bool(int(out[0, k]) == int(top.indices[k, 1]))}
+                "margin_rank_among_positions": rank,
+                "pair_is_top2": {int(out[0, k]), int(v_out[0, k])} == set(top.indices[k, :2].tolist())}
     for name, out, n in (("tree", t_out, n_t), ("chain", s_out, n_s)):
         d = diff_report(name, out, n)
         if d is not None:
             res[f"first_diff_{name}"] = d
-    # every divergence must sit on a sub-ulp-scale margin AND pick the runner-up: anything else is a parity bug
+    # every divergence must sit on a margin of at most 2 fp16 ulps BETWEEN the two tokens chosen: anything else is a parity bug
     res["divergences_explained_by_margin"] = all(
-        (res.get(f"first_diff_{n}") is None) or (res[f"first_diff_{n}"]["margin_ulps"] <= 2 and res[f"first_diff_{n}"]["other_is_top2"])
+        (res.get(f"first_diff_{n}") is None) or (res[f"first_diff_{n}"]["margin_ulps"] <= 2 and res[f"first_diff_{n}"]["pair_is_top2"])
         for n in ("tree", "chain"))
     print(json.dumps(res))
 
