@@ -292,12 +292,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: no event-bracketed rounds (no roofline objects): every round is a graph replay")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="diagnostic: gloo lets several ranks share ONE GPU (with --share-gpu) to exercise the N > 1 code path")
     ap.add_argument("--exchange", default="peer", choices=["peer", "collective"],
                     help="N > 1: how the per-rank attention records travel -- peer stores into IPC mailboxes (graph-capturable, "
                          "default) or one torch.distributed all-gather per attention call")
-    ap.add_argument("--share-gpu", action="store_true", help="diagnostic: every rank uses cuda:0")
+    ap.add_argument("--no-exchange-check", action="store_true", help="skip the 4-round peer-vs-collective cross-check before the clock starts")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="diagnostic: every rank uses cuda:0.  (Full-size kernels of two processes cannot co-reside on one GPU: a rank "
+                         "spinning for its peer's record keeps the peer's attention kernel off the CUs until the wait times out -- "
+                         "the cross-check then moves the run to the collective.)")
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
                          "with one rank, to price its extra launches without a second GPU")
@@ -334,6 +340,7 @@ def main():
     rounds = args.steps + args.warmup
     max_gen = 6 * (rounds + 2) + 16
     max_rows = max_gen + 256
+    exchange_forced = None
     m = build_model(cfg, device, args.agreement, seed=1234)          # replicated weights: same seed on every rank
     m.set_max_gen_len(max_rows)
     m.glide.set_max_gen_len(max_rows)
@@ -344,6 +351,9 @@ def main():
         for layer in m.model.layers:
             layer.self_attn.shard = shard
         m.glide.cross_attn.shard = shard
+        if args.exchange == "peer" and args.share_gpu and world > 1:
+            exchange_forced = "ranks share one GPU: a rank polling for its peer's record keeps the peer's full-size kernels off the CUs"
+            args.exchange = "collective"
         if args.exchange == "peer":
             # records go rank to rank through IPC-mapped mailboxes (csrc/xgmi.hip): the round stays a HIP graph.  Falls
             # back to the library collective (and says so) when the mapping or its self-check fails.
@@ -358,39 +368,99 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pool = EventPool(cfg.num_hidden_layers * args.steps) if rank == 0 else None
-    gpool = GemmPool((4 * cfg.num_hidden_layers + 48) * (args.steps // SAMPLE + 1)) if rank == 0 else None
-    if pool is not None:
-        from longspec_amd import ops as _ops
-        for layer in m.model.layers:
-            layer.self_attn.timing = pool.next
-        _ops.set_linear_timing(gpool.hook)
+    timing = rank == 0 and not args.no_kernel_timing
+    from longspec_amd import ops as _ops
 
-    with torch.inference_mode():
-        st = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
-        st.eos = None                                    # run a fixed number of rounds
-        graphs = st.use_graphs and not args.no_graphs
-        st.use_graphs = graphs
-        if graphs:
-            m.prepare_tree_graphs(st)                    # one HIP graph per accepted-token count, captured before the clock starts
-        for _ in range(args.warmup):
-            m.tree_round(st)
-        barrier()
-        tok0 = st.emitted
+    def fresh_state():
+        s_ = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
+        s_.eos = None                                    # run a fixed number of rounds
+        return s_
+
+    exchange_note = exchange_forced
+    if world > 1 and shard.peer is not None and not args.no_exchange_check:
+        # The peer-store exchange on THIS machine against the library collective, on the real workload: the same four
+        # rounds from the same state, once with each, must emit the same tokens on every rank (and no wait may time out).
+        # Otherwise the run continues on the collective -- a wrong exchange is a wrong benchmark.
+        with torch.inference_mode():
+            peer_obj, shard.peer = shard.peer, None
+            s_ = fresh_state()
+            for _ in range(4):
+                m.tree_round(s_)
+            ref = s_.output_ids[0, :s_.emitted].clone()
+            shard.peer = peer_obj
+            s_ = fresh_state()
+            s_.use_graphs = s_.use_graphs and not args.no_graphs
+            for _ in range(4):
+                m.tree_round(s_)
+            got = s_.output_ids[0, :s_.emitted].clone()
+            ok = got.numel() == ref.numel() and bool(torch.equal(got, ref)) and not shard.peer.status()[1]
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                shard.peer.close()
+                shard.peer = None
+                exchange_note = "peer-store exchange disagreed with the collective on the 4-round cross-check: run continued on the collective"
+                if rank == 0:
+                    print("[bench] " + exchange_note, file=sys.stderr, flush=True)
+            del s_
+
+    def measure():
+        """warm-up + the timed K rounds from a fresh decode state; rank 0 brackets every launch of every 10th round with events"""
+        pool = EventPool(cfg.num_hidden_layers * args.steps) if timing else None
+        gpool = GemmPool((4 * cfg.num_hidden_layers + 48) * (args.steps // SAMPLE + 1)) if timing else None
         if pool is not None:
-            pool.on = gpool.on = True
-        t0 = time.time()
-        for i in range(args.steps):
-            if gpool is not None:                        # launches are bracketed on every 10th round only: two event
-                gpool.on = pool.on = (i % SAMPLE == 0)   # records around each of ~200 launches cost ~2 ms per round
-                st.use_graphs = graphs and not pool.on   # the bracketed rounds are issued launch by launch, the others replayed
-            m.tree_round(st)
-        barrier()
-        elapsed = time.time() - t0
-        if pool is not None:
-            pool.on = gpool.on = False
-            _ops.set_linear_timing(None)
-        tokens = st.emitted - tok0
+            for layer in m.model.layers:
+                layer.self_attn.timing = pool.next
+            _ops.set_linear_timing(gpool.hook)
+        with torch.inference_mode():
+            st = fresh_state()
+            graphs = st.use_graphs and not args.no_graphs
+            st.use_graphs = graphs
+            if graphs:
+                m.prepare_tree_graphs(st)                # one HIP graph per accepted-token count, captured before the clock starts
+            for _ in range(args.warmup):
+                m.tree_round(st)
+            barrier()
+            tok0 = st.emitted
+            if pool is not None:
+                pool.on = gpool.on = True
+            t0 = time.time()
+            for i in range(args.steps):
+                if gpool is not None:                    # launches are bracketed on every 10th round only: two event
+                    gpool.on = pool.on = (i % SAMPLE == 0)   # records around each of ~200 launches cost ~2 ms per round
+                    st.use_graphs = graphs and not pool.on   # the bracketed rounds are issued launch by launch, the others replayed
+                m.tree_round(st)
+            barrier()
+            elapsed = time.time() - t0
+            if pool is not None:
+                pool.on = gpool.on = False
+                _ops.set_linear_timing(None)
+            tokens = st.emitted - tok0
+        agree, detail = True, None
+        if world > 1:                                    # the round is replicated: every rank must have emitted the same tokens
+            chk = torch.tensor([tokens, int(st.output_ids[0, :st.emitted].sum())], dtype=torch.int64, device=device)
+            lo = chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            agree = bool(torch.equal(lo, chk))
+            if not agree:
+                detail = {"tokens_min_max": [int(lo[0]), int(chk[0])], "id_sum_min_max": [int(lo[1]), int(chk[1])]}
+        return SimpleNamespace(elapsed=elapsed, tokens=tokens, st=st, graphs=graphs, pool=pool, gpool=gpool, agree=agree, detail=detail)
+
+    res = measure()
+    if world > 1 and shard.peer is not None:
+        # a wait that timed out (on any rank) or ranks that emitted different tokens void the run: measure again on the collective
+        bad = torch.tensor([int(shard.peer.status()[1] or not res.agree)], dtype=torch.int32, device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            exchange_note = ("peer-store exchange failed during the timed rounds (timeout or rank disagreement): "
+                             "measured again on the collective")
+            if rank == 0:
+                print("[bench] " + exchange_note, file=sys.stderr, flush=True)
+            shard.peer.close()
+            shard.peer = None
+            res = measure()
+    elapsed, tokens, st, graphs, pool, gpool = res.elapsed, res.tokens, res.st, res.graphs, res.pool, res.gpool
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -413,13 +483,18 @@ def main():
         "hip_graphs": bool(graphs and st.graphs is not False),
     }
     if world > 1 or args.shard_path:
-        out["exchange"] = ("peer stores into IPC-mapped mailboxes (csrc/xgmi.hip), 2 launches per attention call" if shard.peer is not None
+        out["exchange"] = ("peer stores into IPC-mapped mailboxes, fused into the two combine kernels of the call (csrc/xgmi.hip)" if shard.peer is not None
                            else "torch.distributed all-gather per attention call")
+        if exchange_note:
+            out["exchange_note"] = exchange_note
         if shard.peer is not None:
             done, timed_out = shard.peer.status()
             out["exchange_calls"], out["exchange_timed_out"] = done, timed_out
-
-    if rank == 0:
+        if world > 1:
+            out["ranks_agree"] = res.agree
+            if res.detail:
+                out["ranks_disagree"] = res.detail
+    if timing:
         # ---- roofline of the kernel north_star names: the hybrid verification attention, stage 1 (this rank's KV shard).
         # achieved = SURVEY 8(d)'s algorithmic bytes of one call / the kernel's average duration, every launch of the timed
         # region's bracketed rounds measured with HIP events recorded by the C ABI on the launch stream.  `traffic` (PMC
@@ -449,7 +524,7 @@ def main():
                                 "gemm_ms_per_round": round(gs["us"] / len(range(0, args.steps, SAMPLE)) / 1e3, 3),
                                 "launches_over_100MB_gbps": round(gs["big_gbps"], 1) if gs["big_gbps"] else None}
         out["attention_ms_per_round"] = round(mean_us * cfg.num_hidden_layers / 1e3, 3)
-    if rank == 0:
+    if timing:
         # ---- the whole round against the HBM roofline: every weight streamed by the six passes (+ their
         # small x / y) as counted on the bracketed rounds, the prefix K/V of the 32 verification calls and of the 5 draft
         # cross-attention calls, the draft's 512-row window.  This rank's bytes over this rank's round time.

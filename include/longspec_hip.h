@@ -325,6 +325,9 @@ int ls_xchg_handle(ls_xchg* x, void* handle /* LS_XCHG_HANDLE_BYTES */);
 int ls_xchg_connect(ls_xchg* x, const void* handles /* world * LS_XCHG_HANDLE_BYTES, rank order */);
 int ls_xchg_all_gather(ls_xchg* x, const float* record, size_t n_floats, float* gathered, size_t stride_floats, void* stream);
 int ls_xchg_status(ls_xchg* x, uint64_t* epoch, int* timed_out); /* synchronising; diagnostics only */
+/* How long a wait polls before it gives up (default about 1 s; rank skew on a node is milliseconds).  Ranks that SHARE
+ * one GPU (tests) stall each other for whole scheduling quanta and need tens of seconds.  Synchronising. */
+int ls_xchg_set_timeout(ls_xchg* x, double seconds);
 /* The same exchange fused into the two combine kernels of a sharded attention call: ls_attn_reduce_push =
  * ls_attn_reduce_local whose record goes straight into the peers' mailboxes (+ flags); ls_attn_finish_xchg =
  * ls_attn_finish over the mailbox slots of this exchange, read once every rank's flag is up.  One exchange =

@@ -93,6 +93,7 @@ SYMBOLS = {
     "ls_xchg_connect": (C.c_int, [_P, _P]),
     "ls_xchg_all_gather": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "ls_xchg_status": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(_I)]),
+    "ls_xchg_set_timeout": (C.c_int, [_P, C.c_double]),
     "ls_xchg_destroy": (C.c_int, [_P]),
     "ls_attn_reduce_push": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P]),
     "ls_attn_finish_xchg": (C.c_int, [C.POINTER(AttnDesc), _P, _P, C.c_size_t, _P]),

@@ -71,12 +71,13 @@ __device__ __forceinline__ float wave_xor_sum_16_32(float v) {
 // ---- peer exchange (xgmi.hip; attn.hip fuses it into the reduce / finish kernels of a sharded attention call) ----
 constexpr int XCHG_MAX_WORLD = LS_XCHG_MAX_WORLD;
 constexpr size_t XCHG_DATA_OFF = 256;             // flags: u64 [2][16] = 256 bytes, then f32 [2][world][cap_floats]
-constexpr unsigned XCHG_SPIN_LIMIT = 4u << 20;    // x s_sleep(32): seconds, not forever -- a dead peer must not hang the GPU
+constexpr unsigned XCHG_SPIN_LIMIT = 1u << 20;    // default, x s_sleep(32) ~ 1 s (rank skew is milliseconds): a dead peer must not hang the GPU
 
 struct XCtl {
     unsigned long long epoch;                      // the NEXT exchange to push; counted on the device (graph replays advance it):
                                                    // a push reads e and leaves e + 1, the wait behind it works on epoch - 1
     unsigned int error;                            // latched: a wait gave up
+    unsigned int spin_limit;                       // polls (x s_sleep(32)) before a wait gives up
     unsigned int arrive_all;
     unsigned int arrive_push[XCHG_MAX_WORLD];
 };
@@ -110,9 +111,10 @@ __device__ __forceinline__ void xchg_raise_flag(char* box, int parity, int rank,
 __device__ __forceinline__ void xchg_wait_flag(const char* box, XCtl* ctl, int parity, int src, unsigned long long epoch) {
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(box) + parity * XCHG_MAX_WORLD + src;
     unsigned spins = 0;
+    if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // latched: never wait twice
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
         __builtin_amdgcn_s_sleep(32);
-        if (++spins > XCHG_SPIN_LIMIT) {
+        if (++spins > ctl->spin_limit) {
             __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

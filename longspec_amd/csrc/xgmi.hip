@@ -86,8 +86,10 @@ int ls_xchg_create(int rank, int world, size_t cap_floats, ls_xchg** out) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->ctl), sizeof(XCtl));
     if (e == hipSuccess) e = hipMemset(x->ctl, 0, sizeof(XCtl));
     if (e == hipSuccess) {
-        const unsigned long long one = 1;          // flags start at 0: the first epoch is 1
-        e = hipMemcpy(&x->ctl->epoch, &one, sizeof(one), hipMemcpyHostToDevice);
+        XCtl c = {};
+        c.epoch = 1;                               // flags start at 0: the first epoch is 1
+        c.spin_limit = XCHG_SPIN_LIMIT;
+        e = hipMemcpy(x->ctl, &c, sizeof(c), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->peers_dev), sizeof(char*) * XCHG_MAX_WORLD);
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -150,6 +152,15 @@ int ls_xchg_all_gather(ls_xchg* x, const float* record, size_t n_floats, float* 
     hipLaunchKernelGGL(xchg_wait_kernel, grid, dim3(XCHG_THREADS), 0, st, x->box, x->ctl, gathered, stride_floats, n16, x->world,
                        x->cap_floats);
     LS_CHECK_LAUNCH("xchg_wait_kernel");
+    return LS_OK;
+}
+
+int ls_xchg_set_timeout(ls_xchg* x, double seconds) {
+    if (!x || !(seconds > 0)) LS_FAIL(LS_ERR_INVALID_ARG, "ls_xchg_set_timeout: null object or non-positive time");
+    const double polls = seconds * 1.0e6;          // one poll = s_sleep(32) + a system-scope load: about a microsecond
+    const unsigned int limit = polls > 4.0e9 ? 4000000000u : (unsigned int)polls;
+    const hipError_t e = hipMemcpy(&x->ctl->spin_limit, &limit, sizeof(limit), hipMemcpyHostToDevice);
+    if (e != hipSuccess) LS_FAIL(LS_ERR_LAUNCH, "ls_xchg_set_timeout: %s", hipGetErrorString(e));
     return LS_OK;
 }
 

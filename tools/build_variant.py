@@ -7,8 +7,8 @@ name, flags = sys.argv[1], sys.argv[2:]
 objs = []
 for src in b.SOURCES:
     obj = os.path.join(b.LIBDIR, src.replace(".hip", ".o"))
-    if src == "attn.hip":
-        obj = os.path.join(b.LIBDIR, f"attn_{name}.o")
+    if src in ("attn.hip", "xgmi.hip"):
+        obj = os.path.join(b.LIBDIR, src.replace(".hip", f"_{name}.o"))
         subprocess.check_call([b._hipcc()] + b.FLAGS + flags + ["-c", os.path.join(b.CSRC, src), "-o", obj])
     objs.append(obj)
 out = os.path.join(b.LIBDIR, f"liblongspec_hip_{name}.so")
