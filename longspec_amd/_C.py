@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# LONGSPEC_HIP_LIB: diagnostic builds of the same library (tools/v2_stamps.py); the product path is the in-tree default
+# LONGSPEC_HIP_LIB: diagnostic builds of the same library (tools/build_variant.py, tools/ws_prof.py); the product path is the in-tree default
 LIB_PATH = os.environ.get("LONGSPEC_HIP_LIB") or os.path.join(HERE, "_lib", "liblongspec_hip.so")
 
 LS_F16, LS_BF16 = 0, 1

@@ -1191,797 +1191,6 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p
     }
 }
 
-// ===================== verification path v2: one wave per SIMD, single role (attn_verify_kernel) ==============
-// The warp-specialised kernel above concentrates the whole soft-max on ONE wave per SIMD (an in-order wave issues at
-// most one instruction every ~4 cycles) and synchronises its S and O waves with a workgroup barrier per 32 keys, right
-// after which both of them wait for LDS operands at the same time.  Here a workgroup is 4 waves, one per SIMD, each
-// with the whole 512-entry register file: a wave owns 80 query rows (5 tiles) end to end -- Q^T (80 registers), the
-// 160 O^T accumulators, two S^T buffers (2 x 40) -- so P never leaves registers and nothing but the K/V ring needs a
-// barrier (one per 64 keys).  The loop is a software pipeline over 32-key blocks in which the matrix pipe always has
-// work queued and every LDS operand is fetched one phase ahead:
-//     phase A(b):  S(b+1) = K(b+1).Q^T   (40 MFMA)  ||  p = 2^((S(b) - m)c) of row tiles 0-2,  V^T(b) fragment reads
-//     phase B(b):  O     += V^T(b).P(b)  (40 MFMA, row tiles 0..4 in order)  ||  p of row tiles 3-4,  K(b+2) fragment reads
-// (two blocks per loop trip so that the S buffers alternate without copies).  The reference maximum m of a row is
-// fixed from the split's first 64 keys (lse = m*scale + ln l holds for any m); a block sum within two octaves of the
-// fp16 range makes the workgroup redo its split with the textbook online soft-max.
-// K/V tiles of 64 keys stream HBM -> LDS through rings of LA+1 (K) and LA+2 (V) slots; a wave issues its 4 K and 4 V
-// pieces of a tile with a wave-uniform base in SGPRs and ONE per-lane offset register each (the source-side swizzle of
-// a wave's pieces does not depend on the piece).
-// The tree part (LS_NEW_TARGET) runs in the workgroup of split 0 before its -- correspondingly shorter -- key range:
-// all 296 rows at once, QK^T of the <= 96 new keys kept in registers (one sweep instead of three).
-constexpr int V2_QT = 5;                          // row tiles per wave (4 waves: 320 rows)
-constexpr int V2_LA = 2;                          // 64-key tiles of DMA look-ahead
-constexpr int V2_NSK = V2_LA + 1;                 // ring slots: tile X (K keys 64X+32 .. 64X+95, V keys 64X .. 64X+63 of the
-constexpr int V2_NSV = V2_LA + 1;                 // split) is read during trip X only
-constexpr int V2_TILE_B = 64 * ROWB;              // 16 KB: 64 keys of K (or V)
-constexpr int V2_RING_B = (V2_NSK + V2_NSV) * V2_TILE_B;   // 96 KB
-constexpr int V2_K0_B = 32 * ROWB;                // the split's first 32 keys of K (read by the prologue only)
-constexpr int V2_QL_OFF = V2_RING_B + V2_K0_B + 64 + V2_QT * 256 * 4;   // Q^T fragments of k-steps 2, 3: 10 x 1 KB per wave
-constexpr int V2_QL_B = 4 * 2 * V2_QT * 1024;
-constexpr int V2_STAMP_OFF = V2_QL_OFF + V2_QL_B;
-#ifdef LS_V2_STAMPS
-constexpr int V2_LDS = V2_STAMP_OFF + 4096;      // diagnostic build: s_memtime stamps of one wave (tools/v2_stamps.py)
-#else
-constexpr int V2_LDS = V2_STAMP_OFF;
-#endif
-constexpr int V2_NEW_KEYS = 96;                   // tree part: new keys held in registers as 3 blocks of 32
-constexpr int V2_TREE_TILES = 6;                  // 64-key tiles the tree part is worth (split 0 gets that many fewer)
-
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
-
-template <typename E>
-struct V2 {
-    using V8 = typename E::V8;
-    static constexpr int QT = V2_QT;
-
-    // ---- operand fetches ----
-    static __device__ __forceinline__ void load_k(V8 (&kf)[4][2], const LaneTbl& tb, unsigned kbase) {
-        int kx = tb.kx;
-        asm volatile("" : "+v"(kx));           // see qk_block
-        const unsigned kb = kbase + tb.kb;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
-    }
-    static __device__ __forceinline__ void load_v(V8 (&vf)[8], const LaneTbl& tb, unsigned vbase) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        int vx = tb.vx;
-        asm volatile("" : "+v"(vx));
-        const unsigned vb = vbase + tb.vb;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            const unsigned va = vb + ((dt ^ vx) << 5);
-            union {
-                struct { s16x4 a, b; } s;
-                V8 v;
-            } u;
-            u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
-            u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
-            vf[dt] = u.v;
-        }
-    }
-    static __device__ __forceinline__ void qk(f32x4 (&s)[2][QT], const V8 (&kf)[4][2], const V8 (&qf)[QT][4]) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[k4][kt], qf[qt][k4], s[kt][qt]);
-    }
-    // soft-max numerators of row tile qt of one block against the fixed reference (nmc = -m*c): P in the B-operand
-    // register image, row sums, overflow watch.  nvalid < 32: keys >= nvalid of the block lie beyond the cache end.
-    template <bool MASKED>
-    static __device__ __forceinline__ void softmax_tile(const f32x4 (&s)[2][QT], int qt, float c, float nmc, float& lsum,
-                                                        float& pmax, V8& pf, int nvalid, int g4) {
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, nmc));
-                if (MASKED && kt * 16 + g4 * 4 + e >= nvalid) pe = 0.f;
-                ps += pe;
-                pf[kt * 4 + e] = E::from_f32(pe);
-            }
-        lsum += ps;
-        pmax = fmaxf(pmax, ps);                // sum of 8 probabilities: a conservative stand-in for their max
-    }
-    static __device__ __forceinline__ void pv_tile(f32x4 (&acc)[8][QT], int qt, const V8 (&vf)[8], const V8& pf) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = E::mfma(vf[dt], pf, acc[dt][qt]);
-    }
-};
-
-
-#ifndef V2_STAMP_WAVE
-#define V2_STAMP_WAVE 0
-#endif
-template <typename E>
-__global__ __launch_bounds__(256, 1) void attn_verify_kernel(const AttnK p) {
-    using X = V2<E>;
-    using V8 = typename E::V8;
-    constexpr int QT = V2_QT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int l15, g4;
-    const int split = blockIdx.x, kvh = blockIdx.y, bi = blockIdx.z;
-    const int L = p.cache_seqlens[bi];
-    const float c = p.scale * LOG2E;
-    const int row0 = wave * QT * 16;
-    // Per-lane constants (fragment addresses, DMA source offsets) are RE-DERIVED from an opaque copy of the lane id at the
-    // start of every program region instead of being carried from kernel entry: a value that lives through the register-
-    // hungry tree part and the prologue gets spilled, and its reload inside the key loop would come with a compiler-
-    // inserted s_waitcnt vmcnt(0) that drains the hand-counted DMA look-ahead on every trip.
-    LaneTbl tb;
-    unsigned koff, voff;
-    int kq, pos;
-    auto lane_consts = [&]() {
-        int ln = threadIdx.x & 63;
-        asm volatile("" : "+v"(ln));
-        l15 = ln & 15;
-        g4 = ln >> 4;
-        tb = make_lane_tbl(l15, g4);
-        kq = ln >> 4;
-        pos = ln & 15;
-        koff = (unsigned)(kq * (p.kc_ss * 2)) + ((pos ^ ((wave << 2) | kq)) << 4);
-        voff = (unsigned)(kq * (p.kc_ss * 2)) + ((pos ^ ((((wave & 1) << 2) | kq) << 1)) << 4);
-    };
-    lane_consts();
-    int rrow[QT], rhead[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        rrow[qt] = m < p.M ? m % p.sq : 0;         // padding rows: computed, never stored
-        rhead[qt] = kvh * p.g + (m < p.M ? m / p.sq : 0);
-    }
-    typedef __attribute__((address_space(3))) char lds_char;
-    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;
-    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const long kc_row = p.kc_ss * 2;
-    int* redo_flag = reinterpret_cast<int*>(smem + V2_RING_B + V2_K0_B);
-
-    V8 qf[QT][4];
-    auto load_q = [&](bool prescale) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow[qt] * p.q_ss +
-                                      (long)rhead[qt] * p.q_sh + g4 * 8;
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                V8 v = *reinterpret_cast<const V8*>(qp + k4 * 32);
-                if (prescale) {   // `query_states * self.softmax_scale` in the activation dtype (llama.py:407)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = E::from_f32(E::to_f32(v[e]) * p.scale);
-                }
-                qf[qt][k4] = v;
-            }
-        }
-    };
-    f32x4 acc[8][QT];
-    auto acc_zero = [&]() {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-
-    // ================= tree part (LS_NEW_TARGET), workgroup of split 0 =================
-    // LlamaAttention.tree_part_fwd numerics (llama.py:406-415): QK^T rounded to the activation dtype, scaled before (last
-    // layer, G1) or after the product, fp32 soft-max over the visible new keys, probabilities rounded before P.V (G2).
-    if (p.has_new && split == 0) {
-        const int n_new = p.n_new;
-        const char* kn_base = reinterpret_cast<const char*>(p.k_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
-        const char* vn_base = reinterpret_cast<const char*>(p.v_new) + ((long)bi * p.kn_sb + (long)kvh * p.kn_sh) * 2;
-        const long kn_row = p.kn_ss * 2;
-        if (p.scatter_new) {       // the new K/V rows go into the caches (llama.py:396-399)
-            char* kw = reinterpret_cast<char*>(p.k_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-            char* vw = reinterpret_cast<char*>(p.v_cache_w) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-            const int n_rows = n_new - p.n_new_cached;
-            for (int idx = tid; idx < n_rows * 16; idx += 256) {
-                const int i = idx >> 4, ch = idx & 15;
-                const long dst = (long)(L + p.n_new_cached + i) * kc_row;
-                reinterpret_cast<uint4*>(kw + dst)[ch] = reinterpret_cast<const uint4*>(kn_base + (long)i * kn_row)[ch];
-                reinterpret_cast<uint4*>(vw + dst)[ch] = reinterpret_cast<const uint4*>(vn_base + (long)i * kn_row)[ch];
-            }
-        }
-        // all new keys -> LDS (K at 0, V at 24 KB), mask words and the (pre-scaled) Q under the DMA latency
-        char* ldsK = smem;
-        char* ldsV = smem + V2_NEW_KEYS * ROWB;
-        tile_dma(ldsK, ldsV, wave, lane, 4, V2_NEW_KEYS / 4, [&](int key, const char*& kp, const char*& vp) {
-            const int j = min(key, n_new - 1);            // tail rows: masked by zero bits
-            if (j < p.n_new_cached) {
-                kp = kc_base + (long)(L + j) * kc_row;
-                vp = vc_base + (long)(L + j) * kc_row;
-            } else {
-                kp = kn_base + (long)(j - p.n_new_cached) * kn_row;
-                vp = vn_base + (long)(j - p.n_new_cached) * kn_row;
-            }
-        });
-        uint32_t mw[QT][3];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int m = row0 + qt * 16 + l15;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                mw[qt][j] = (m < p.M && j < p.mask_words) ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + j] : 0u;
-        }
-        load_q(p.prescale_q != 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const unsigned vbase0 = smem_a + V2_NEW_KEYS * ROWB;
-        // scores of all 3 blocks in registers: sv[blk][kt][qt]
-        f32x4 sv[3][2][QT];
-#pragma unroll
-        for (int blk = 0; blk < 3; ++blk) {
-            V8 kf[4][2];
-            X::load_k(kf, tb, smem_a + blk * 32 * ROWB);
-            X::qk(sv[blk], kf, qf);
-        }
-        float tmax[QT], tsum[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int blk = 0; blk < 3; ++blk)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float xs = round_to<E>(sv[blk][kt][qt][e]);
-                        if (!p.prescale_q) xs = round_to<E>(xs * p.scale);
-                        xs = ((mw[qt][blk] >> (kt * 16 + g4 * 4 + e)) & 1u) ? xs : -INFINITY;
-                        sv[blk][kt][qt][e] = xs;
-                        mx = fmaxf(mx, xs);
-                    }
-            tmax[qt] = wave_xor_max_16_32(mx);
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float mref = tmax[qt] == -INFINITY ? 0.f : tmax[qt];
-            float ts = 0.f;
-#pragma unroll
-            for (int blk = 0; blk < 3; ++blk)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ex = expf(sv[blk][kt][qt][e] - mref);
-                        sv[blk][kt][qt][e] = ex;
-                        ts += ex;
-                    }
-            tsum[qt] = wave_xor_sum_16_32(ts);
-        }
-        acc_zero();
-#pragma unroll
-        for (int blk = 0; blk < 3; ++blk) {
-            V8 vf[8];
-            X::load_v(vf, tb, vbase0 + blk * 32 * ROWB);
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float den = tsum[qt] > 0.f ? tsum[qt] : 1.f;
-                V8 pf;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pf[kt * 4 + e] = E::from_f32(sv[blk][kt][qt][e] / den);
-                X::pv_tile(acc, qt, vf, pf);
-            }
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int m = row0 + qt * 16 + l15;
-            if (m < p.M) {
-                float* op = p.new_o + (((long)bi * p.sq + rrow[qt]) * p.H + rhead[qt]) * D + g4 * 4;
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    f32x4 o = acc[dt][qt];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = round_to<E>(o[e]);     // fp16 matmul result (llama.py:414)
-                    *reinterpret_cast<f32x4*>(op + dt * 16) = o;
-                }
-                if (g4 == 0)
-                    p.new_lse[((long)bi * p.H + rhead[qt]) * p.sq + rrow[qt]] =
-                        tsum[qt] > 0.f ? tmax[qt] + logf(tsum[qt]) : -INFINITY;   // logsumexp (llama.py:415)
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // the ring is free again
-    }
-
-    // ================= prefix split =================
-    // tiles of 64 keys; split 0 carries V2_TREE_TILES fewer when it also did the tree part
-    const int t1 = (L + 63) >> 6;
-    const int comp = p.has_new ? V2_TREE_TILES : 0;
-    const int tps = (t1 + comp + p.n_splits - 1) / p.n_splits;
-    const int tps0 = max(tps - comp, 0);
-    const int t_begin = split == 0 ? 0 : tps0 + (split - 1) * tps;
-    const int NT = max(0, min(t1, t_begin + (split == 0 ? tps0 : tps)) - t_begin);    // tiles of this split
-    const int last_key = L - 1;
-    const int key_end = L - t_begin * 64;          // valid keys counted from the split's first key (may exceed NT*64)
-
-    // ---- DMA: wave w moves pieces w, w+4, w+8, w+12 of a tile's 16 K and 16 V pieces (a piece = 4 keys = 1 KB).
-    // The K part of tile X starts 32 keys later than its V part (S is computed one block ahead of P.V), so that both
-    // parts are read during trip X only; the split's first 32 keys of K have their own slot (dma_k0).
-    lane_consts();
-    auto dma_part = [&](const char* base, long key0, int npieces, unsigned off, bool is_v, unsigned lds_a, char* lds_p) {
-        if (key0 + npieces * 16 <= L) {             // fast path: wave-uniform base, one per-lane offset register
-            const char* pb = base + (key0 + wave * 4) * kc_row;
-            for (int i = 0; i < npieces; ++i) dma16_s(pb + (long)i * 16 * kc_row, off, lds_a + wave * 1024 + i * 4096);
-        } else {                                     // crosses the end of the cache: re-read the last key (masked later)
-            for (int i = 0; i < npieces; ++i) {
-                const int key = (wave + 4 * i) * 4 + kq;
-                const long ka = min(key0 + key, (long)last_key);
-                const int sw = is_v ? ((key & 7) << 1) : (key & 15);
-                dma16(base + ka * kc_row + ((pos ^ sw) << 4), lds_p + (wave + 4 * i) * 1024);
-            }
-        }
-    };
-    auto dma_tile = [&](int X, int kshift) {      // X = tile index within the split; 8 pieces per wave, always
-        const long key0 = (long)(t_begin + X) * 64;
-        const int ks = (X % V2_NSK) * V2_TILE_B, vs = (V2_NSK + X % V2_NSV) * V2_TILE_B;
-        dma_part(kc_base, key0 + kshift, 4, koff, false, smem_a + ks, smem + ks);
-        dma_part(vc_base, key0, 4, voff, true, smem_a + vs, smem + vs);
-    };
-    // ONE piece (i = 0..3) of the K (is_v = 0) or V part of tile X: the main loop spreads a tile's 8 pieces over a trip
-    auto dma_piece = [&](int X, int is_v, int i) {
-        const long key0 = (long)(t_begin + X) * 64 + (is_v ? 0 : 32);
-        const int slot = is_v ? (V2_NSK + X % V2_NSV) * V2_TILE_B : (X % V2_NSK) * V2_TILE_B;
-        const char* base = is_v ? vc_base : kc_base;
-        if (key0 + 64 <= L) {
-            dma16_s(base + (key0 + wave * 4 + (long)i * 16) * kc_row, is_v ? voff : koff, smem_a + slot + wave * 1024 + i * 4096);
-        } else {
-            const int key = (wave + 4 * i) * 4 + kq;
-            const long ka = min(key0 + key, (long)last_key);
-            const int sw = is_v ? ((key & 7) << 1) : (key & 15);
-            dma16(base + ka * kc_row + ((pos ^ sw) << 4), smem + slot + (wave + 4 * i) * 1024);
-        }
-    };
-    auto dma_piece_fast = [&](int X, int is_v, int i) {       // the same for a tile known to lie inside the cache: no branch
-        const long key0 = (long)(t_begin + X) * 64 + (is_v ? 0 : 32);
-        const int slot = is_v ? (V2_NSK + X % V2_NSV) * V2_TILE_B : (X % V2_NSK) * V2_TILE_B;
-        dma16_s((is_v ? vc_base : kc_base) + (key0 + wave * 4 + (long)i * 16) * kc_row, is_v ? voff : koff,
-                smem_a + slot + wave * 1024 + i * 4096);
-    };
-    auto dma_k0 = [&]() { dma_part(kc_base, (long)t_begin * 64, 2, koff, false, smem_a + V2_RING_B, smem + V2_RING_B); };
-    // LDS byte address of K / V block blk (32 keys) of the split; K block 0 lives in its own slot
-    auto k_addr = [&](int blk) -> unsigned {
-        return blk == 0 ? smem_a + V2_RING_B : smem_a + (((blk - 1) >> 1) % V2_NSK) * V2_TILE_B + ((blk - 1) & 1) * 32 * ROWB;
-    };
-    auto v_addr = [&](int blk) -> unsigned { return smem_a + (V2_NSK + (blk >> 1) % V2_NSV) * V2_TILE_B + (blk & 1) * 32 * ROWB; };
-    // wait until tile `need` has landed; `issued` = tiles issued so far (8 pieces per wave each, in order)
-    auto wait_tile = [&](int need, int issued) { wait_vmcnt(need < issued ? 8 * (issued - 1 - need) : 0); };
-
-    float mref[QT], lsum[QT];
-    if (NT > 0) {
-        load_q(false);
-        dma_k0();
-        const int n0 = min(NT, V2_LA);
-        for (int X = 0; X < min(n0, 2); ++X) dma_tile(X, 32);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) asm volatile("" : "+v"(qf[qt][k4]));     // Q, K block 0 and tiles 0, 1 have landed
-        __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        {   // Q^T fragments of k-steps 2, 3 -> LDS, fragment-major and lane-linear (each lane reads back only its own 16 bytes)
-            typedef __attribute__((address_space(3))) V8 lds_v8w;
-            const unsigned qb = smem_a + V2_QL_OFF + wave * (2 * QT * 1024) + lane * 16;
-#pragma unroll
-            for (int k4 = 2; k4 < 4; ++k4)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) *(lds_v8w*)(uintptr_t)(qb + ((k4 - 2) * QT + qt) * 1024) = qf[qt][k4];
-        }
-
-        const int nblk = min(NT * 2, (key_end + 31) >> 5);       // 32-key blocks of the split that hold valid keys
-        f32x4 sA[2][QT], sB[2][QT];
-        V8 pf[QT];   // (tail / redo paths)
-        auto mask_tail = [&](f32x4 (&s)[2][QT], int blk) {
-            const int nv = key_end - blk * 32;
-            if (nv < 32) {
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (kt * 16 + g4 * 4 + e >= nv) s[kt][qt][e] = -INFINITY;
-            }
-        };
-        auto row_max = [&](const f32x4 (&s)[2][QT], float (&mx)[QT]) {
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float v = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                                      fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-                mx[qt] = fmaxf(mx[qt], wave_xor_max_16_32(v));
-            }
-        };
-        // ---- reference look: row maxima over the split's first 64 keys; S(0) stays in sA
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            mref[qt] = -INFINITY;
-            lsum[qt] = 0.f;
-        }
-        // K fragments are fetched one k-step (10 MFMAs) ahead, V^T fragments two d-tiles (10 MFMAs) ahead -- 16 + 12
-        // registers instead of 32 + 32
-        V8 kfa[2], kfb[2], vfr[3];
-        auto k_frag = [&](V8 (&kfx)[2], unsigned kbase, int k4) {
-            int kx = tb.kx;
-            asm volatile("" : "+v"(kx));
-            const unsigned ka = kbase + tb.kb + ((k4 ^ kx) << 6);
-            kfx[0] = lds_read16<V8>(ka);
-            kfx[1] = lds_read16<V8>(ka + 16 * ROWB);
-        };
-        auto qk_jit = [&](f32x4 (&sS)[2][QT], unsigned kbase) {          // sS = K(block).Q^T
-            k_frag(kfa, kbase, 0);
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                V8 (&cur)[2] = (k4 & 1) ? kfb : kfa;
-                V8 (&nxt)[2] = (k4 & 1) ? kfa : kfb;
-                if (k4 < 3) k_frag(nxt, kbase, k4 + 1);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-                        sS[kt][qt] = E::mfma(cur[kt], qf[qt][k4], k4 == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sS[kt][qt]);
-            }
-        };
-        if (nblk > 1) {
-            qk_jit(sB, k_addr(1));
-            mask_tail(sB, 1);
-            row_max(sB, mref);
-        }
-        qk_jit(sA, k_addr(0));
-        mask_tail(sA, 0);
-        row_max(sA, mref);
-        float nmc[QT];
-        float* mref_lds = reinterpret_cast<float*>(smem + V2_RING_B + V2_K0_B + 64) + tid;   // parked across the loop: every
-#pragma unroll                                                                              // register counts there
-        for (int qt = 0; qt < QT; ++qt) {
-            nmc[qt] = -(mref[qt] == -INFINITY ? 0.f : mref[qt]) * c;
-            mref_lds[qt * 256] = mref[qt];
-        }
-        acc_zero();
-        float pmax = 0.f;
-
-        // ---- one loop trip = one 64-key tile T (blocks b0 = 2T, b0 + 1); entering: sA = S(b0).
-        auto v_frag = [&](V8& vfx, unsigned vbase, int dt) {
-            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-            int vx = tb.vx;
-            asm volatile("" : "+v"(vx));
-            const unsigned va = vbase + tb.vb + ((dt ^ vx) << 5);
-            union {
-                struct { s16x4 a, b; } s;
-                V8 v;
-            } u;
-            u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
-            u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
-            vfx = u.v;
-        };
-        // ---- the pipeline.  What the hardware allows was measured (tools/v2_stamps.py, tools/mb/mfma_rate.hip):
-        //  * a vector-ALU instruction that touches the register half an in-flight MFMA writes waits for that MFMA: S^T read
-        //    out of accumulation registers among MFMAs cost ~25 cycles per v_accvgpr_read, and with S^T accumulated in
-        //    architectural registers every soft-max instruction interleaved with the QK^T MFMAs stalled (2.5x slower);
-        //  * pure arithmetic is placed anywhere by instruction selection (all 40 exp2 of a block in one batch), so every
-        //    instruction whose position matters is an asm statement; sched_barrier pins the rest.
-        // Hence, per 32-key block b:
-        //   QK phase : sS = K(b+1).Q^T -- 40 MFMAs back to back into accumulation registers, nothing but the operand
-        //              fetches between them (K fragments one k-step ahead; the Q^T fragments of k-steps 2, 3 from LDS);
-        //   hand-over: the 40 scores leave the accumulation registers in one burst (the matrix pipe is empty for it);
-        //   PV phase : O^T += V^T(b).P^T(b) -- 40 MFMAs writing accumulation registers -- with the soft-max of block b+1
-        //              (architectural registers only: fma, exp2, sum, packed conversion, one score per MFMA, the three
-        //              instructions of a score one step apart) under them -> P(b+1).
-        // All MFMAs are asm with TIED accumulators (the builtin's result may land in another register quad than its addend:
-        // 160 copies back at the loop edge) and chosen register halves: O^T 160 + S^T 40 + Q^T(k-steps 0, 1) 40 = 240
-        // accumulation registers; the scores' copy, two P buffers and the operand fragments are architectural.
-        // The 8 DMA pieces of the tile issued in a trip are spread over its four MFMA phases.
-        V8 qL[4], pfX[QT], pfY[QT];
-        float sv[8 * QT];
-        const unsigned ql_base = smem_a + V2_QL_OFF + wave * (2 * QT * 1024) + lane * 16;
-        auto mfma_s = [&](f32x4& sreg, const V8& kfrag, const V8& qfrag, auto k4c) {
-            constexpr int k4 = decltype(k4c)::value;
-            if constexpr (std::is_same<E, ElemF16>::value) {
-                if constexpr (k4 == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(sreg) : "v"(kfrag), "a"(qfrag));
-                else if constexpr (k4 == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sreg) : "v"(kfrag), "a"(qfrag));
-                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(sreg) : "v"(kfrag), "v"(qfrag));
-            } else {
-                if constexpr (k4 == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(sreg) : "v"(kfrag), "a"(qfrag));
-                else if constexpr (k4 == 1) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sreg) : "v"(kfrag), "a"(qfrag));
-                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(sreg) : "v"(kfrag), "v"(qfrag));
-            }
-        };
-        auto mfma_o = [&](f32x4& areg, const V8& vfrag, const V8& pfrag) {
-            if constexpr (std::is_same<E, ElemF16>::value)
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(areg) : "v"(vfrag), "v"(pfrag));
-            else
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(areg) : "v"(vfrag), "v"(pfrag));
-        };
-        // QK phase + hand-over.  The k-step-0 fragments were requested into kfa by the caller / the preceding PV phase.
-        auto phase_qk = [&](unsigned kbase, unsigned vbase_next, auto&& dma2) {
-            constexpr int QL_AHEAD = 3;
-            auto step = [&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                constexpr int k4 = m / 10, qt = (m % 10) >> 1, kt = m & 1;
-                V8 (&cur)[2] = (k4 & 1) ? kfb : kfa;
-                V8 (&nxt)[2] = (k4 & 1) ? kfa : kfb;
-                if (m % 10 == 0) {
-                    if (k4 < 3) k_frag(nxt, kbase, k4 + 1);
-                    else {
-                        v_frag(vfr[0], vbase_next, 0);
-                        v_frag(vfr[1], vbase_next, 1);
-                    }
-                }
-                if (m == 12) dma2(0);
-                if (m == 32) dma2(1);
-                if (kt == 0) {                               // the LDS-resident Q^T fragment needed QL_AHEAD row tiles from now
-                    constexpr int freq = (m / 2) + QL_AHEAD - 2 * QT;
-                    if constexpr (freq >= 0 && freq < 2 * QT) qL[freq & 3] = lds_read16<V8>(ql_base + freq * 1024);
-                }
-                if constexpr (k4 < 2) mfma_s(sA[kt][qt], cur[kt], qf[qt][k4], std::integral_constant<int, k4>{});
-                else mfma_s(sA[kt][qt], cur[kt], qL[((k4 - 2) * QT + qt) & 3], std::integral_constant<int, k4>{});
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            static_for<40>(step);
-            // hand-over: the last MFMA needs its 4 passes (+ write-back) before the first read
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 8 * QT; ++i) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv[i]) : "a"(sA[(i & 7) >> 2][i >> 3][i & 3]));
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // PV phase: O^T += V^T(blk).pIn, fragments 0 and 1 of V^T already requested into vfr[0], vfr[1];  SM: soft-max of sv
-        // -> pOut under the MFMAs;  KPRE: near its end the k-step-0 fragments of the next QK phase (same K tile)
-        auto phase_pv = [&](const V8 (&pIn)[QT], V8 (&pOut)[QT], unsigned vbase, unsigned kbase_next, auto smc, auto kpre, auto&& dma2) {
-            constexpr bool SM = decltype(smc)::value, KPRE = decltype(kpre)::value;
-            float tt[2], ee[4], ps = 0.f;
-            unsigned pw[4];
-            const float c_ = c;
-            float nm_[QT];
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) nm_[qt] = nmc[qt];
-            auto sm_fma = [&](int i) {                       // compile-time i after unrolling
-                if (!SM || i < 0 || i >= 40) return;
-                const float sval = sv[i], nval = nm_[i >> 3];
-                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(tt[i & 1]) : "v"(sval), "v"(c_), "v"(nval));
-            };
-            auto sm_exp = [&](int i) {
-                if (!SM || i < 0 || i >= 40) return;
-                asm volatile("v_exp_f32 %0, %1" : "=v"(ee[i & 3]) : "v"(tt[i & 1]));
-            };
-            auto sm_fin = [&](int i) {
-                if (!SM || i < 0 || i >= 40) return;
-                const int qt = i >> 3, j = i & 7;
-                if (j == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(ps) : "v"(ee[i & 3]));
-                else asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps) : "v"(ee[i & 3]));
-                if (j & 1) {
-                    if constexpr (std::is_same<E, ElemF16>::value)
-                        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pw[j >> 1]) : "v"(ee[(i - 1) & 3]), "v"(ee[i & 3]));
-                    else
-                        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pw[j >> 1]) : "v"(ee[(i - 1) & 3]), "v"(ee[i & 3]));
-                }
-                if (j == 7) {
-                    asm volatile("v_add_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %2" : "+v"(lsum[qt]), "+v"(pmax) : "v"(ps));
-                    union {
-                        unsigned u[4];
-                        V8 v;
-                    } cv;
-                    cv.u[0] = pw[0]; cv.u[1] = pw[1]; cv.u[2] = pw[2]; cv.u[3] = pw[3];
-                    pOut[qt] = cv.v;
-                }
-            };
-            sm_fma(0);
-            sm_exp(0);
-            sm_fma(1);
-#pragma unroll
-            for (int m = 0; m < 40; ++m) {
-                const int dt = m / 5, qt = m % 5;
-                if (qt == 0) {
-                    if (dt + 2 < 8) v_frag(vfr[(dt + 2) % 3], vbase, dt + 2);
-                    else if (KPRE && dt == 6) k_frag(kfa, kbase_next, 0);
-                }
-                if (m == 7) dma2(0);
-                if (m == 27) dma2(1);
-                mfma_o(acc[dt][qt], vfr[dt % 3], pIn[qt]);
-                sm_fin(m);                                   // score m: sum / conversion;  m+1: exp2;  m+2: fma
-                sm_exp(m + 1);
-                sm_fma(m + 2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-#ifdef LS_V2_STAMPS
-        unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + V2_STAMP_OFF);
-#define V2_STAMP(i)                                                                                      \
-    do {                                                                                                 \
-        if (T >= 8 && T < 40 && wave == V2_STAMP_WAVE) {                                                 \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                  \
-            if (lane == 0) stamps[(T - 8) * 8 + (i)] = t_;                                               \
-        }                                                                                                \
-    } while (0)
-#else
-#define V2_STAMP(i)
-#endif
-        // one loop trip = one 64-key tile T (blocks b0 = 2T, b0 + 1); entering: pfX = P(b0).  FINAL (the last pipelined
-        // trip): nothing is computed for block b0 + 2
-        auto trip = [&](int T, auto steady, auto final_) {
-            constexpr bool ST = decltype(steady)::value, FIN = decltype(final_)::value;
-            V2_STAMP(0);
-            // tile T (K blocks 2T+1, 2T+2 and V blocks 2T, 2T+1) has landed once at most the LA-1 younger tiles are in flight
-            if constexpr (ST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (V2_LA - 1)) : "memory");
-            else wait_tile(T, min(NT, T + V2_LA));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's LDS reads of trip T-1 have returned
-            V2_STAMP(1);
-            __builtin_amdgcn_s_barrier();                       // everyone's pieces landed; trip T-1 is over everywhere
-            V2_STAMP(2);
-            const int b0 = 2 * T;
-            const bool issue = T + V2_LA < NT;                  // tile T+LA goes into the slots of tile T-1
-            const int TX = T + V2_LA;
-            auto piece = [&](int is_v, int i) {
-                if constexpr (ST) dma_piece_fast(TX, is_v, i);
-                else if (issue) dma_piece(TX, is_v, i);
-            };
-            k_frag(kfa, k_addr(b0 + 1), 0);
-            V2_STAMP(3);
-            phase_qk(k_addr(b0 + 1), v_addr(b0), [&](int h) { piece(0, h); });                                   // S(b0+1)
-            V2_STAMP(4);
-            phase_pv(pfX, pfY, v_addr(b0), k_addr(b0 + 2), std::true_type{}, std::integral_constant<bool, !FIN>{},
-                     [&](int h) { piece(0, 2 + h); });                                                           // O += V P(b0) || P(b0+1)
-            V2_STAMP(5);
-            if constexpr (!FIN) phase_qk(k_addr(b0 + 2), v_addr(b0 + 1), [&](int h) { piece(1, h); });           // S(b0+2)
-            else {
-                v_frag(vfr[0], v_addr(b0 + 1), 0);
-                v_frag(vfr[1], v_addr(b0 + 1), 1);
-                piece(1, 0);
-                piece(1, 1);
-            }
-            V2_STAMP(6);
-            phase_pv(pfY, pfX, v_addr(b0 + 1), 0u, std::integral_constant<bool, !FIN>{}, std::false_type{},
-                     [&](int h) { piece(1, 2 + h); });                                                           // O += V P(b0+1) || P(b0+2)
-            V2_STAMP(7);
-        };
-        // Only the LAST tile of the LAST split can cross the end of the cache: it is peeled off the pipeline and done
-        // block by block with the key mask (its K block 2T is still in the slot of tile T-1: nothing was issued over it).
-        const bool tail_masked = key_end < NT * 64;
-        const int n_fast = tail_masked ? NT - 1 : NT;
-        lane_consts();
-        // Nothing the compiler knows of may be pending in the vector-memory queue when the loop starts: its waitcnt pass
-        // would otherwise put s_waitcnt vmcnt(k) in front of first uses INSIDE the loop (a register reloaded from scratch
-        // in the preheader is enough), and vmcnt is the counter the DMA look-ahead is counted on.  The builtin, unlike
-        // an asm statement, is visible to that pass.
-        __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): simm16 = vmcnt 0 | expcnt 7 << 4 | lgkmcnt 15 << 8
-        for (int X = 2; X < n0; ++X) dma_tile(X, 32);           // tiles 2.. are first read two trips from here
-        // steady trips: LA-1 younger tiles are in flight and the tile issued (T + LA) exists and lies inside the cache
-        // (its K part ends 96 keys after its first key); the last trips count down / clamp, with branches
-        const int x_in = (int)min((long)NT - 1, ((long)L - 96) / 64 - t_begin);
-        const int n_steady = max(0, min(n_fast - 1, x_in - V2_LA + 1));
-        if (n_fast > 0) {
-            // P(0): the soft-max of the split's first block (its scores are still in sA from the look)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) X::template softmax_tile<false>(sA, qt, c, nmc[qt], lsum[qt], pmax, pfX[qt], 32, g4);
-#pragma unroll 1
-            for (int T = 0; T < n_steady; ++T) trip(T, std::true_type{}, std::false_type{});
-#pragma unroll 1
-            for (int T = n_steady; T < n_fast - 1; ++T) trip(T, std::false_type{}, std::false_type{});
-            trip(n_fast - 1, std::false_type{}, std::true_type{});
-        }
-        if (tail_masked) {
-            const int T = NT - 1;
-            wait_tile(T, NT);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            load_q(false);          // a fresh copy: the fragments of the main loop need not survive into this register-hungry tail
-#pragma unroll 1
-            for (int blk = 2 * T; blk < nblk; ++blk) {
-                V8 vf[8];
-                qk_jit(sA, k_addr(blk));
-                X::load_v(vf, tb, v_addr(blk));
-                const int nv = key_end - blk * 32;
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    X::template softmax_tile<true>(sA, qt, c, nmc[qt], lsum[qt], pmax, pf[qt], nv, g4);
-                    X::pv_tile(acc, qt, vf, pf[qt]);
-                }
-            }
-        }
-#ifdef LS_V2_STAMPS
-        __syncthreads();
-        if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && tid < 256)
-            reinterpret_cast<unsigned long long*>(p.new_o)[tid] = stamps[tid];
-#endif
-        lane_consts();
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) mref[qt] = mref_lds[qt * 256];
-        // ---- overflow watch: redo the split with the textbook online soft-max (rare: a key scoring e^9.7 above the
-        // maximum of the split's first 64 keys)
-        if (tid == 0) *redo_flag = 0;
-        __syncthreads();
-        if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;         // fp16 tops out at 65504
-        __syncthreads();
-        if (*redo_flag) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            load_q(false);          // see the tail
-            acc_zero();
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                mref[qt] = -INFINITY;
-                lsum[qt] = 0.f;
-            }
-            const int m0 = min(NT, V2_LA);
-            for (int X = 0; X < m0; ++X) dma_tile(X, 0);           // here K and V parts of a tile cover the same 64 keys
-#pragma unroll 1
-            for (int T = 0; T < NT; ++T) {
-                wait_tile(T, min(NT, T + V2_LA));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (T + V2_LA < NT) dma_tile(T + V2_LA, 0);
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {
-                    const int blk = 2 * T + h;
-                    if (blk >= nblk) break;
-                    V8 vf[8];
-                    qk_jit(sA, smem_a + (T % V2_NSK) * V2_TILE_B + h * 32 * ROWB);
-                    mask_tail(sA, blk);
-                    X::load_v(vf, tb, v_addr(blk));
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        float mx = fmaxf(fmaxf(fmaxf(sA[0][qt][0], sA[0][qt][1]), fmaxf(sA[0][qt][2], sA[0][qt][3])),
-                                         fmaxf(fmaxf(sA[1][qt][0], sA[1][qt][1]), fmaxf(sA[1][qt][2], sA[1][qt][3])));
-                        mx = wave_xor_max_16_32(mx);
-                        const float m_new = fmaxf(mref[qt], mx);
-                        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-                        if (__any(m_new > mref[qt])) {
-                            const float alpha = __builtin_amdgcn_exp2f((mref[qt] - m_safe) * c);
-                            lsum[qt] *= alpha;
-#pragma unroll
-                            for (int dt = 0; dt < 8; ++dt) acc[dt][qt] *= alpha;
-                            mref[qt] = m_new;
-                        }
-                        float dummy = 0.f;
-                        X::template softmax_tile<false>(sA, qt, c, -m_safe * c, lsum[qt], dummy, pf[qt], 32, g4);
-                        X::pv_tile(acc, qt, vf, pf[qt]);
-                    }
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            mref[qt] = -INFINITY;
-            lsum[qt] = 0.f;
-        }
-        acc_zero();
-    }
-
-    // ---- write the normalised partial ------------------------------------------
-    int lane2 = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane2));              // row ids are recomputed here instead of being carried through the loop
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const float lt = wave_xor_sum_16_32(lsum[qt]);
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        const float lse = lt > 0.f ? mref[qt] * p.scale + __logf(lt) : -INFINITY;
-        const int m = row0 + qt * 16 + (lane2 & 15);
-        if (m < p.M) {
-            const int rrow_q = m % p.sq, rhead_q = kvh * p.g + m / p.sq;
-            float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow_q) * p.H + rhead_q) * D + (lane2 >> 4) * 4;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
-            if ((lane2 >> 4) == 0) p.parts_lse[(((long)split * p.b + bi) * p.H + rhead_q) * p.sq + rrow_q] = lse;
-        }
-    }
-}
-
 // ---- stage 2: combine + merge ----------------------------------------------------------
 struct FinK {
     const float* parts_o;    // [n_parts][b][sq][H][D]
@@ -2209,23 +1418,17 @@ __global__ void pack_mask_kernel(const int64_t* mask, int M, int N, uint32_t* bi
 struct Cfg {
     int qtA, qtB, rbA, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
     int ws;        // warp-specialised prefix path (attn_partial_ws_kernel)
-    int v2;        // one-wave-per-SIMD verification path (attn_verify_kernel)
 };
 
 // Workgroup shape for M = g*sq rows sharing one K/V stream (see the header comment).
 // The warp-specialised kernel takes the verification-sized row blocks (17..20 tiles) of calls whose prefix has
 // no causal / window edge (every row sees keys [0, L)) and whose new block fits its smaller ring.
-// Which streaming kernel serves verification-sized row blocks: LS_ATTN_KERNEL = ws (default) | v2 | general, read ONCE
-// per process (A/B switch of the benchmarks).  v2 = attn_verify_kernel, the one-wave-per-SIMD experiment of round 2: it is
-// NOT faster than the warp-specialised kernel (DESIGN.md section 8.2 has the measurements and why) and one prefix case
-// of tests/test_gpu_ops.py fails under it -- opt-in for further work only, never the product default.
+// Which streaming kernel serves verification-sized row blocks: LS_ATTN_KERNEL = ws (default) | general, read ONCE per
+// process (A/B switch of the benchmarks).
 int kernel_choice() {
     static const int choice = [] {
         const char* e = getenv("LS_ATTN_KERNEL");
-        if (!e) return 1;
-        if (e[0] == 'v') return 2;
-        if (e[0] == 'g') return 0;
-        return 1;
+        return e && e[0] == 'g' ? 0 : 1;
     }();
     return choice;
 }
@@ -2235,17 +1438,9 @@ bool ws_eligible(const ls_attn_desc* d) {
     return d->causal == 0 && d->window_left < 0 && (d->new_mode == LS_NEW_NONE || d->n_new <= WS_NEW_CAP / 64 * 64);
 }
 
-bool v2_eligible(const ls_attn_desc* d) {
-    if (kernel_choice() < 2) return false;
-    if (d->causal != 0 || d->window_left >= 0) return false;
-    if (d->new_mode == LS_NEW_NONE) return true;
-    return d->new_mode == LS_NEW_TARGET && d->n_new <= V2_NEW_KEYS && d->n_new_cached == 0;
-}
-
-Cfg pick_cfg(int M, bool ws_ok, bool v2_ok = false) {
+Cfg pick_cfg(int M, bool ws_ok) {
     Cfg c;
     c.ws = 0;
-    c.v2 = 0;
     int tiles = (M + 15) / 16;
     c.row_chunks = 1;
     if (tiles > 24) {                   // g*sq > 384 rows: several row chunks re-read the K/V stream
@@ -2272,12 +1467,6 @@ Cfg pick_cfg(int M, bool ws_ok, bool v2_ok = false) {
         c.nstages = WS_NEW_CAP / c.tile;            // the new-block workgroup's capacity in the smaller ring
         c.lds = WS_LDS;
     }
-    if (v2_ok && tiles > 16 && tiles <= 20 && c.row_chunks == 1) {
-        c.ws = 0;
-        c.v2 = 1;
-        c.threads = 256;
-        c.lds = V2_LDS;
-    }
     return c;
 }
 
@@ -2303,7 +1492,7 @@ int pick_splits(const ls_attn_desc* d, const Cfg& c) {
     const int wg_per_split = d->Hkv * c.row_chunks * d->b;
     // one workgroup per CU in total: the new-block workgroups (one per kv head) count too, otherwise the
     // surplus prefix workgroups start only when a CU frees up and the launch takes two rounds
-    int target = num_cus() / wg_per_split - (d->new_mode != LS_NEW_NONE && !c.v2 ? 1 : 0);
+    int target = num_cus() / wg_per_split - (d->new_mode != LS_NEW_NONE ? 1 : 0);
     if (target < 1) target = 1;
     int s = target < tiles ? target : tiles;
     if (s > 512) s = 512;
@@ -2376,19 +1565,7 @@ int launch_partial_ws(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
 }
 
 template <typename E>
-int launch_verify(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    auto fn = attn_verify_kernel<E>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr;
-    hipLaunchKernelGGL(fn, grid, dim3(c.threads), c.lds, s, k);
-    LS_CHECK_LAUNCH("attn_verify_kernel");
-    return LS_OK;
-}
-
-template <typename E>
 int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    if (c.v2) return launch_verify<E>(c, k, grid, s);
     if (c.ws) return launch_partial_ws<E>(c, k, grid, s);
     if (c.qtA == 1) return launch_partial<E, 1, 1>(c, k, grid, s);
     if (c.qtA == 2) return launch_partial<E, 2, 2>(c, k, grid, s);
@@ -2400,7 +1577,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     int rc = validate(d);
     if (rc) return rc;
     const int g = d->H / d->Hkv;
-    const Cfg c = pick_cfg(g * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(g * d->sq, ws_eligible(d));
     const int n_splits = pick_splits(d, c);
     const WsLayout w = ws_layout(d, c, n_splits);
     if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -2439,7 +1616,7 @@ int run_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, hipStream_t s,
     k.q_sb = d->q_stride_b; k.q_ss = d->q_stride_s; k.q_sh = d->q_stride_h;
     k.kc_sb = d->kc_stride_b; k.kc_ss = d->kc_stride_s; k.kc_sh = d->kc_stride_h;
     k.kn_sb = d->kn_stride_b; k.kn_ss = d->kn_stride_s; k.kn_sh = d->kn_stride_h;
-    dim3 grid(c.v2 ? n_splits : n_splits + k.has_new, d->Hkv * c.row_chunks, d->b);
+    dim3 grid(n_splits + k.has_new, d->Hkv * c.row_chunks, d->b);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     rc = d->dtype == LS_F16 ? dispatch_partial<ElemF16>(c, k, grid, s) : dispatch_partial<ElemBF16>(c, k, grid, s);
     if (d->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s);
@@ -2493,20 +1670,20 @@ extern "C" {
 
 size_t ls_attn_workspace_bytes(const ls_attn_desc* d) {
     if (validate(d)) return 0;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     return ws_layout(d, c, pick_splits(d, c)).total;
 }
 
 int ls_attn_num_parts(const ls_attn_desc* d) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     return pick_splits(d, c) * c.KS;
 }
 
 const char* ls_attn_kernel_name(const ls_attn_desc* d) {
     if (validate(d)) return "invalid";
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
-    return c.v2 ? "attn_verify_kernel" : c.ws ? "attn_partial_ws_kernel" : "attn_partial_kernel";
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
+    return c.ws ? "attn_partial_ws_kernel" : "attn_partial_kernel";
 }
 
 int ls_attn_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) {
@@ -2530,7 +1707,7 @@ int ls_attn_fwd(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) 
 int ls_attn_reduce_local(const ls_attn_desc* d, void* ws, size_t ws_bytes, float* o32, float* lse, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!o32 || !lse) LS_FAIL(LS_ERR_INVALID_ARG, "o32/lse null");
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
     char* base = static_cast<char*>(ws);
@@ -2542,7 +1719,7 @@ int ls_attn_finish(const ls_attn_desc* d, const float* parts_o, const float* par
                    int64_t part_lse_stride, void* ws, size_t ws_bytes, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!parts_o || !parts_lse || n_parts < 1 || !d->out) LS_FAIL(LS_ERR_INVALID_ARG, "parts/out null");
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     const bool has_new = d->new_mode != LS_NEW_NONE;
     if (has_new && (!ws || ws_bytes < w.total)) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -2562,7 +1739,7 @@ static int xchg_fits(const ls_attn_desc* d, const ls_xchg* x) {
 int ls_attn_reduce_push(const ls_attn_desc* d, void* ws, size_t ws_bytes, ls_xchg* x, void* stream) {
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (xchg_fits(d, x)) return LS_ERR_INVALID_ARG;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     if (!ws || ws_bytes < w.total) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
     char* base = static_cast<char*>(ws);
@@ -2574,7 +1751,7 @@ int ls_attn_finish_xchg(const ls_attn_desc* d, ls_xchg* x, void* ws, size_t ws_b
     if (validate(d)) return LS_ERR_INVALID_ARG;
     if (!d->out) LS_FAIL(LS_ERR_INVALID_ARG, "out null");
     if (xchg_fits(d, x)) return LS_ERR_INVALID_ARG;
-    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), v2_eligible(d));
+    const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d));
     const WsLayout w = ws_layout(d, c, pick_splits(d, c));
     const bool has_new = d->new_mode != LS_NEW_NONE;
     if (has_new && (!ws || ws_bytes < w.total)) LS_FAIL(LS_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, w.total);
