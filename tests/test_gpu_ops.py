@@ -427,8 +427,32 @@ def test_full_size_properties_qwq_bf16_32k(ops):
 
 
 # --------------------------------------------------------------------------- #
-# BASELINE sizes: size-independent properties
+# BASELINE sizes: the whole hybrid call against the oracle, then size-independent properties
 # --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("L,last_layer", [(16384, False), (131072, False), (131072 - 21, True)])
+def test_full_size_verify_attention_vs_oracle(ops, L, last_layer):
+    """The metric's own sizes (Llama-3-8B heads, 74 rows, 16k and 128k prefixes, one ragged length): prefix
+    flash-decoding + KV scatter + tree-masked part + fp16 merge of the HIP path against the OpenMP C restatement of the
+    reference (oracle/oracle_c.c, ~1 s of host time per call at 128k) -- not a property: element by element."""
+    from oracle import c_port
+    H, Hkv = 32, 8
+    q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 4000 + L % 97, a=4)
+    gen = torch.Generator(device="cpu").manual_seed(L)
+    kc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    vc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    kc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(torch.float16)
+    vc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(torch.float16)
+    kc_r, vc_r = kc.clone(), vc.clone()
+    ref = c_port.verify_attention(q, k, v, kc_r, vc_r, L, tm, last_layer)
+    kc_g, vc_g = g(kc), g(vc)
+    cl = torch.tensor([L], dtype=torch.int32)
+    out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), last_layer, kv_len_hint=L)
+    assert_close_f16(out, ref, atol=2.1e-3, what=f"L={L}")
+    assert torch.equal(kc_g[:, L:L + 74].cpu(), kc_r[:, L:L + 74]) and torch.equal(vc_g[:, L:L + 74].cpu(), vc_r[:, L:L + 74])
+    assert torch.equal(kc_g[:, :L].cpu(), kc[:, :L])
+
+
+
 @pytest.mark.parametrize("L", [16384, 131072])
 def test_full_size_properties(ops, L):
     """Llama-3-8B heads at 16k / 128k prefix: (1) LSE-merge of two half-prefix calls ==
