@@ -296,11 +296,13 @@ int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int ma
  *   (base = cache_lens - input_len); cache_lens += correct_len; draft_cache_lens = cache_lens - (correct_len == gamma+1);
  *   next_spec_start_token [b,2] = (llm[correct_len-2], llm[correct_len-1]) when every draft was accepted, else [0] = bonus;
  *   spec_buffer[z,0] = bonus; state [b,2] = (correct_len, any(output_ids[z, :base+correct_len+2] == eos)).
- * llm_verify_output / spec_buffer [b, gamma+1] int64 (both updated in place), lengths int32. */
+ * llm_verify_output / spec_buffer [b, gamma+1] int64 (both updated in place), lengths int32.
+ * accept_mask [b, gamma] int64 or NULL: at temperature > 0 the verification is the cumulative product of the rejection-
+ * sampling verdicts (:725-732) instead of the token comparison (:738). */
 int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int gamma, int64_t* output_ids,
                     int64_t out_stride, int out_cap, int32_t* cache_lens, int32_t* draft_cache_lens,
                     const int32_t* input_len, int64_t* next_spec_start_token, int has_eos, int64_t eos,
-                    int64_t* state, void* stream);
+                    int64_t* state, const int64_t* accept_mask, void* stream);
 
 /* `embed_tokens(ids)` of a short pass (llama.py:579, llama_glide.py:1003,1030): out [n,hidden] =
  * table[ids] (table [vocab,hidden] dtype, ids int64 inside the vocabulary). */

@@ -261,13 +261,15 @@ __global__ __launch_bounds__(64) void chain_commit_kernel(int64_t* __restrict__ 
                                                           int64_t* __restrict__ output_ids, long out_stride, int out_cap,
                                                           int32_t* cache_lens, int32_t* draft_cache_lens,
                                                           const int32_t* __restrict__ input_len, int64_t* __restrict__ next_start,
-                                                          int has_eos, int64_t eos, int64_t* __restrict__ state) {
+                                                          int has_eos, int64_t eos, int64_t* __restrict__ state,
+                                                          const int64_t* __restrict__ accept) {
     const int z = blockIdx.x, lane = threadIdx.x;
     int64_t* l = llm + (long)z * (G + 1);
     int64_t* sp = spec + (long)z * (G + 1);
     int64_t* out = output_ids + (long)z * out_stride;
     // lane i < G: does draft token i+1 match the target's prediction after token i?  correct = leading matches
-    const bool match = lane < G ? (l[lane] == sp[lane + 1]) : false;
+    // (temperature > 0: the rejection-sampling verdicts of llama_glide.py:725-732 instead of the comparison)
+    const bool match = lane < G ? (accept ? accept[(long)z * G + lane] != 0 : l[lane] == sp[lane + 1]) : false;
     const unsigned long long bal = __ballot(match);
     const int lead = __ffsll((long long)~bal) - 1;                      // first lane that does not match (>= 0: lane G never does)
     const int correct = lead + 1;                                       // 1 .. G+1
@@ -560,14 +562,15 @@ int ls_tree_commit(const int64_t* acc_ids, const int64_t* acc_num, int b, int ma
 
 int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int gamma, int64_t* output_ids,
                     int64_t out_stride, int out_cap, int32_t* cache_lens, int32_t* draft_cache_lens, const int32_t* input_len,
-                    int64_t* next_spec_start_token, int has_eos, int64_t eos, int64_t* state, void* stream) {
+                    int64_t* next_spec_start_token, int has_eos, int64_t eos, int64_t* state, const int64_t* accept_mask,
+                    void* stream) {
     if (!llm_verify_output || !spec_buffer || !output_ids || !cache_lens || !draft_cache_lens || !input_len ||
         !next_spec_start_token || !state)
         LS_FAIL(LS_ERR_INVALID_ARG, "chain_commit: null pointer");
     if (b < 1 || gamma < 1 || gamma > 62 || out_cap < 1) LS_FAIL(LS_ERR_INVALID_ARG, "chain_commit: gamma=%d out_cap=%d", gamma, out_cap);
     hipLaunchKernelGGL(chain_commit_kernel, dim3(b), dim3(64), 0, static_cast<hipStream_t>(stream), llm_verify_output,
                        spec_buffer, gamma, output_ids, (long)out_stride, out_cap, cache_lens, draft_cache_lens, input_len,
-                       next_spec_start_token, has_eos, eos, state);
+                       next_spec_start_token, has_eos, eos, state, accept_mask);
     LS_CHECK_LAUNCH("chain_commit_kernel");
     return LS_OK;
 }

@@ -371,10 +371,10 @@ class LlamaGlide(LlamaForCausalLM):
 
     def _chain_generate(self, input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter):
         assert input_ids is not None, "please give the input"
-        if temperature > 0:
-            raise NotImplementedError("chain speculation at temperature > 0 (llama_glide.py:716-736 rejection sampling over "
-                                      "spec_logits) is not implemented: the tree method's verify_stochastic is")
         magic = drafter == "magicdec"
+        if temperature > 0 and magic:
+            raise NotImplementedError("magicdec_generate at temperature > 0 (llama_glide.py:854-875) is not implemented; "
+                                      "spec_generate and tree_spec_generate are")
         self._clear_shard()
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
@@ -396,6 +396,10 @@ class LlamaGlide(LlamaForCausalLM):
         draft_cache_lens = cache_lens.clone()
         spec_buffer = output_ids.new_zeros((bsz, gamma + 1))
         spec_buffer[:, 0] = output_ids[:, 0]
+        # temperature > 0 (:639-640,704,709): the draft's fp32 logits of every step, for the rejection test of :716-736
+        spec_logits = logits.new_zeros((bsz, gamma + 1, logits.size(-1)), dtype=torch.float32) if temperature > 0 else None
+        if spec_logits is not None:
+            spec_logits[:, 0] = logits
         if not magic:                                    # glide prefill
             hidden_states = self.model.embed_tokens(input_ids)
             position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
@@ -443,16 +447,25 @@ class LlamaGlide(LlamaForCausalLM):
                     draft_cache_lens += 2                    # 1 + double_input (batch 1: the host knows the flag)
                     current_logp = self.lm_head(hidden_states[:, -2:, :])
                     spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp)[:, 1]
+                    if spec_logits is not None:
+                        spec_logits[:, spec_steps + 1, :] = current_logp[:, 1, :]
                 else:
                     draft_cache_lens += 1
                     current_logp = self.lm_head(hidden_states[:, -1, :])
                     spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp).view(-1,)
+                    if spec_logits is not None:
+                        spec_logits[:, spec_steps + 1, :] = current_logp
             hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
-            llm_verify_output = self.ops.argmax_rows(self.lm_head(hidden_states[:, -gamma - 1:, :]))
+            llm_verify_logits = self.lm_head(hidden_states[:, -gamma - 1:, :])
+            llm_verify_output = self.ops.argmax_rows(llm_verify_logits)
+            accept = None
+            if temperature > 0:                              # :715-736
+                llm_verify_output, accept = self.ops.chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer,
+                                                                             llm_verify_output)
             # acceptance by cumulative match, verified ids + bonus token -> output_ids, cache_lens += correct_len, the next
             # round's start tokens and draft_cache_lens = cache_lens - double_input (:738-770): one launch, one host read
             state = self.ops.chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len_i32,
-                                          next_spec_start_token, eos).tolist()
+                                          next_spec_start_token, eos, **({"accept_mask": accept} if accept is not None else {})).tolist()
             n_ok, hit = state[0][0], any(row[1] for row in state)
             double_flag = n_ok == gamma + 1
             count += n_ok - 1

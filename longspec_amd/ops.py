@@ -889,10 +889,40 @@ def tree_commit(acc_ids, acc_num, output_ids, emitted: int, eos: Optional[int], 
     return state
 
 
+stochastic_uniform_fn = None   # tests replay the reference's CPU generator: fn(shape, device) -> U[0,1) fp32
+stochastic_chain_noise_fn = None   # fn(shape, dtype, device) -> Exponential(1) of the model dtype
+
+
+def chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer, llm_verify_output):
+    """The temperature > 0 branch of ``spec_generate`` (``llama_glide.py:715-736``): accept drafted token i with probability
+    ``min(1, p_i / q_i)`` (q = soft-max of the draft's fp32 logits, p = soft-max of the target's logits in the model dtype,
+    neither divided by the temperature -- as the reference), a rejected position takes one draw from p
+    (``Categorical(p).sample()`` = ``argmax(p / p.sum / Exponential(1))``).  Rewrites ``llm_verify_output[:, :-1]`` in
+    place and returns it with the accept mask [b, gamma] int64 for ``chain_commit``.  A handful of library kernels on
+    gamma x V elements: this branch is not on the metric's path."""
+    _dev(spec_logits, llm_verify_logits, spec_buffer, llm_verify_output)
+    b, g1, V = llm_verify_logits.shape
+    gamma = g1 - 1
+    q_probs = torch.softmax(spec_logits[:, 1:, :], dim=-1)
+    p_probs = torch.softmax(llm_verify_logits[:, :-1, :], dim=-1)
+    idx = spec_buffer[:, 1:].unsqueeze(-1)
+    alpha = torch.clip((torch.gather(p_probs, -1, idx).squeeze(-1) + 1e-9) / (torch.gather(q_probs, -1, idx).squeeze(-1) + 1e-9), 0.0, 1.0)
+    u = stochastic_uniform_fn(alpha.shape, alpha.device) if stochastic_uniform_fn is not None else torch.rand_like(alpha)
+    accept = u.lt(alpha)
+    p2 = p_probs.reshape(-1, V)
+    pn = p2 / p2.sum(-1, keepdim=True)
+    nz = (stochastic_chain_noise_fn(pn.shape, pn.dtype, pn.device) if stochastic_chain_noise_fn is not None
+          else torch.empty_like(pn).exponential_(1))
+    resample = (pn / nz).argmax(dim=-1).reshape(b, gamma)
+    llm_verify_output[:, :-1] = torch.where(accept, spec_buffer[:, 1:], resample)
+    return llm_verify_output, accept.to(torch.int64).contiguous()
+
+
 def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token,
-                 eos: Optional[int]) -> torch.Tensor:
-    """End of a chain-speculation round (``llama_glide.py:738-770``) in one launch: acceptance by cumulative match, the
-    verified ids + bonus token into ``output_ids``, the length bookkeeping and the next round's start tokens, in place.
+                 eos: Optional[int], accept_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """End of a chain-speculation round (``llama_glide.py:738-770``) in one launch: acceptance by cumulative match (or, at
+    temperature > 0, by the cumulative product of ``accept_mask``, ``:732``), the verified ids + bonus token into
+    ``output_ids``, the length bookkeeping and the next round's start tokens, in place.
     Returns state [b,2] int64 = (correct_len, EOS hit) -- the round's one host read."""
     _dev(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token)
     b, g1 = llm_verify_output.shape
@@ -903,13 +933,16 @@ def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_c
         raise ValueError("chain_commit: spec_buffer [b, gamma+1], next_spec_start_token [b, 2]")
     if output_ids.dtype != torch.int64 or output_ids.stride(1) != 1:
         raise TypeError("chain_commit: output_ids must be int64 with contiguous rows")
+    if accept_mask is not None and (accept_mask.dtype != torch.int64 or not accept_mask.is_contiguous() or tuple(accept_mask.shape) != (b, g1 - 1)):
+        raise TypeError("chain_commit: accept_mask must be a contiguous int64 [b, gamma] tensor")
     state = torch.empty((b, 2), dtype=torch.int64, device=output_ids.device)
     lib = _C.load()
     _C.check(lib.ls_chain_commit(llm_verify_output.data_ptr(), spec_buffer.data_ptr(), b, g1 - 1, output_ids.data_ptr(),
                                  output_ids.stride(0), output_ids.shape[1], _len_i32(cache_lens, b, "cache_lens"),
                                  _len_i32(draft_cache_lens, b, "draft_cache_lens"), _len_i32(input_len, b, "input_len"),
                                  next_spec_start_token.data_ptr(), 0 if eos is None else 1, 0 if eos is None else int(eos),
-                                 state.data_ptr(), _stream()), "ls_chain_commit")
+                                 state.data_ptr(), accept_mask.data_ptr() if accept_mask is not None else None, _stream()),
+             "ls_chain_commit")
     return state
 
 

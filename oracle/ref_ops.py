@@ -585,3 +585,32 @@ def verify_stochastic(input_ids, tree_mask, p_llm, p_ssm, temperature: float, dr
         acc_num[z] = len(path)
         acc_ids[z, :len(path)] = torch.tensor(path, dtype=acc_ids.dtype)
     return acc_ids, acc_num
+
+
+def chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer, llm_verify_output, uniform=None, noise=None):
+    """The temperature > 0 branch of ``spec_generate`` (``longspec/test/llama_glide.py:715-736``): the greedy chain draft
+    ``spec_buffer[:, 1:]`` is accepted position by position with probability ``min(1, p / q)`` at the drafted token, where
+    ``q = softmax(spec_logits[:, 1:])`` (fp32) and ``p = softmax(llm_verify_logits[:, :-1])`` in the model dtype (the
+    temperature itself is not applied to either -- as in the reference); a rejected position takes one draw from ``p``.
+    Returns ``(llm_verify_output, accept_mask)``: ``llm_verify_output[:, :-1]`` rewritten in place as ``:727-731`` does;
+    the caller forms ``verification = accept_mask.cumprod(-1)`` (``:732``).
+    Random draws, in the reference's order on torch's global generator: ``rand_like(alpha)`` [b, gamma] fp32, then the one
+    ``exponential_`` of ``Categorical(p).sample()`` = ``multinomial(p / p.sum, 1)`` = ``argmax(pn / noise)``,
+    noise [b * gamma, V] in the model dtype.  ``uniform`` / ``noise`` inject them (tests); default = draw here."""
+    b, g1, V = llm_verify_logits.shape
+    gamma = g1 - 1
+    q_probs = torch.softmax(spec_logits[:, 1:, :], dim=-1)
+    p_probs = torch.softmax(llm_verify_logits[:, :-1, :], dim=-1)
+    idx = spec_buffer[:, 1:].unsqueeze(-1)
+    q_tok = torch.gather(q_probs, -1, idx).squeeze(-1)
+    p_tok = torch.gather(p_probs, -1, idx).squeeze(-1)
+    eps = 1e-9
+    alpha = torch.clip((p_tok + eps) / (q_tok + eps), 0.0, 1.0)
+    u = torch.rand_like(alpha) if uniform is None else uniform
+    accept = u.lt(alpha)
+    p2 = p_probs.reshape(-1, V)
+    pn = p2 / p2.sum(-1, keepdim=True)                     # Categorical.__init__ normalises
+    nz = torch.empty_like(pn).exponential_(1) if noise is None else noise
+    resample = (pn / nz).argmax(dim=-1).reshape(b, gamma)
+    llm_verify_output[:, :-1] = torch.where(accept, spec_buffer[:, 1:], resample)
+    return llm_verify_output, accept

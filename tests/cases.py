@@ -189,3 +189,19 @@ def stochastic_runs():
                    tree_shape=[int(x) for x in g[f"{name}_tree_shape"]], temperature=float(g[f"{name}_temperature"]),
                    out=_t(g[f"{name}_out"]), count=int(g[f"{name}_count"]), num=int(g[f"{name}_num"]),
                    tr_acc_ids=_t(g[f"{name}_tr_acc_ids"]), tr_acc_num=_t(g[f"{name}_tr_acc_num"]), family="llama")
+
+
+def chain_stochastic_runs():
+    """spec_generate(temperature > 0) of the reference on two toy models (tests/golden/make_golden.py::gen_chain_stochastic)."""
+    g = load_golden("chain_stochastic")
+    for name in [str(x) for x in g["runs"]]:
+        over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
+        cfg = toy.toy_config(**over)
+        wseed = int(g[f"{name}_wseed"])
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=float(g[f"{name}_agreement"]))
+        assert toy.state_checksum(tgt) + toy.state_checksum(drf) == cksum_str(g[f"{name}_weights_checksum"]), \
+            "RNG drift: regenerate goldens"
+        yield dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]), wseed=wseed,
+                   prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]),
+                   temperature=float(g[f"{name}_temperature"]), torch_seed=int(g[f"{name}_torch_seed"]),
+                   out=_t(g[f"{name}_out"]), count=int(g[f"{name}_count"]), num=int(g[f"{name}_num"]), family="llama")

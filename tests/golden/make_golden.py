@@ -400,6 +400,36 @@ def gen_verify_stochastic(llama, llama_glide):
         })
     save("verify_stochastic", n_cases=N_STOCHASTIC, runs=np.array(["t_mixed", "t_gqa"], dtype="U32"), **arrays)
 
+def gen_chain_stochastic(llama, llama_glide):
+    """spec_generate(temperature > 0) end to end (llama_glide.py:715-736): rejection sampling of the greedy chain draft against
+    the target's distribution.  Randomness = torch's global CPU generator: per round one rand_like [b, gamma] (fp32), then
+    Categorical(p).sample() = multinomial(p, 1) = one exponential_ of shape [b * gamma, V] in the model dtype."""
+    arrays = {}
+    names = []
+    for name, over, wseed, agree, plen, glen, T in [
+            ("c_mixed", {}, 21, 0.05, 100, 48, 0.7),
+            ("c_gqa", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 23, 0.3, 77, 40, 1.0)]:
+        cfg = toy.toy_config(**over)
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
+        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        ids = toy.make_prompt(cfg, plen, 200 + wseed)
+        pl = torch.tensor([plen])
+        torch.manual_seed(9000 + wseed)
+        with torch.inference_mode():
+            out, count, num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=glen, temperature=T)
+        print(f"[{name}] T={T} count={int(count)} num={int(num)} out={out[0, :12].tolist()}")
+        names.append(name)
+        arrays.update({
+            f"{name}_cfg_keys": np.array(sorted(over.keys()), dtype="U32"),
+            f"{name}_cfg_vals": np.array([over[k] for k in sorted(over.keys())], dtype=np.int64),
+            f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
+            f"{name}_temperature": T, f"{name}_torch_seed": 9000 + wseed,
+            f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
+            f"{name}_prompt": ids, f"{name}_out": out, f"{name}_count": int(count), f"{name}_num": int(num),
+        })
+    save("chain_stochastic", runs=np.array(names, dtype="U32"), **arrays)
+
+
 # --------------------------------------------------------------------------- #
 # G-g: RMSNorm / RoPE from transformers
 # --------------------------------------------------------------------------- #
@@ -703,6 +733,9 @@ def main():
     if "--only-stochastic" in sys.argv:
         gen_verify_stochastic(llama, llama_glide)
         return
+    if "--only-chain-stochastic" in sys.argv:
+        gen_chain_stochastic(llama, llama_glide)
+        return
     if "--only-qwen2-bf16" in sys.argv:
         gen_generate(llama, llama_glide, family="qwen2_bf16")
         return
@@ -716,6 +749,7 @@ def main():
     gen_generate(llama, llama_glide)
     gen_generate(llama, llama_glide, family="qwen2")
     gen_baselines(llama, llama_glide)
+    gen_chain_stochastic(llama, llama_glide)
     install_triton_stubs()          # after model construction
     gen_triton_tree(triton_tree_attn)
     gen_draft_attention(llama_glide)

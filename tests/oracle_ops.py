@@ -110,12 +110,21 @@ def tree_commit(acc_ids, acc_num, output_ids, emitted, eos, tree_mask, all_spec,
     return torch.stack([acc_num, hit], dim=1)
 
 
-def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token, eos):
-    """llama_glide.py:738-770 with the reference's tensor ops (batch 1, as the reference)."""
+def chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer, llm_verify_output):
+    return ref_ops.chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer, llm_verify_output)
+
+
+def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len, next_spec_start_token, eos,
+                 accept_mask=None):
+    """llama_glide.py:738-770 with the reference's tensor ops (batch 1, as the reference); ``accept_mask`` = the T > 0
+    branch's verification source (:732) instead of the token comparison (:738)."""
     bsz, g1 = llm_verify_output.shape
     gamma = g1 - 1
     rows = torch.arange(bsz)
-    verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)       # :738-740
+    if accept_mask is not None:
+        verification = accept_mask.to(torch.int64).cumprod(dim=-1)                         # :732
+    else:
+        verification = llm_verify_output[:, :-1].eq(spec_buffer[:, 1:]).cumprod(dim=-1)   # :738-740
     correct_len = verification.sum(dim=-1) + 1
     llm_verify_output[:, 1:] = llm_verify_output[:, 1:] * verification
     col = (cache_lens - input_len).long().unsqueeze(1) + torch.arange(1, gamma + 1)

@@ -150,3 +150,22 @@ def test_tree_spec_generate_with_temperature_matches_reference(run):
     assert torch.equal(torch.cat(trace["ids"], 0), run["tr_acc_ids"])
     assert (int(count), int(num)) == (run["count"], run["num"])
     assert torch.equal(out.cpu(), run["out"])
+
+
+@pytest.mark.parametrize("run", list(cases.chain_stochastic_runs()), ids=lambda r: r["name"])
+def test_spec_generate_with_temperature_matches_reference(run):
+    """spec_generate(temperature=T) on the HIP kernels: the reference's seeded run token for token.  The two random
+    streams of a round (one rand_like, one exponential_ in the model dtype) are replayed from torch's CPU generator."""
+    from longspec_amd import ops
+    m = build(run)
+    ops.stochastic_uniform_fn = lambda shape, device: torch.rand(shape, dtype=torch.float32).to(device)
+    ops.stochastic_chain_noise_fn = lambda shape, dtype, device: torch.empty(shape, dtype=dtype).exponential_(1).to(device)
+    try:
+        torch.manual_seed(run["torch_seed"])
+        out, count, num, _, _ = m.spec_generate(run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"), gamma=4,
+                                                max_gen_len=run["max_gen_len"], temperature=run["temperature"])
+    finally:
+        ops.stochastic_uniform_fn = None
+        ops.stochastic_chain_noise_fn = None
+    assert (int(count), int(num)) == (run["count"], run["num"])
+    assert torch.equal(out.cpu(), run["out"])

@@ -152,3 +152,16 @@ def test_tree_spec_generate_with_temperature_matches_reference(run):
     assert torch.equal(torch.cat(trace["ids"], 0), run["tr_acc_ids"])
     assert (int(count), int(num)) == (run["count"], run["num"])
     assert torch.equal(out, run["out"])
+
+
+@pytest.mark.parametrize("run", list(cases.chain_stochastic_runs()), ids=lambda r: r["name"])
+def test_spec_generate_with_temperature_matches_reference(run):
+    """The chain method at temperature > 0 (llama_glide.py:715-736): greedy draft chain, rejection test min(1, p/q) against
+    one rand_like per round, resampling from the target's distribution -- the reference's seeded run token for token.  The
+    host loop draws from torch's global generator in the reference's order (oracle/ref_ops.py::chain_accept_stochastic)."""
+    m = build(run)
+    torch.manual_seed(run["torch_seed"])
+    out, count, num, _, _ = m.spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
+                                            max_gen_len=run["max_gen_len"], temperature=run["temperature"])
+    assert (int(count), int(num)) == (run["count"], run["num"])
+    assert torch.equal(out, run["out"])
