@@ -269,6 +269,12 @@ __device__ __forceinline__ void dma16_s(const char* base_uniform, unsigned lane_
                  : "memory", "m0");
 }
 
+// A wave must not end with LDS DMA of its own still in flight (look-ahead tiles it issued and never needed): the
+// workgroup's LDS is handed to the next workgroup on the CU as soon as its waves are gone, and a late global_load_lds
+// then lands in THAT workgroup's tiles.  One dispatch round (<= 256 workgroups: every decode call) never shows it; a
+// batch of 64 identical elements did (tools/bench_prefill.py history).
+__device__ __forceinline__ void drain_lds_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <typename F>
 __device__ __forceinline__ void tile_dma(char* ldsK, char* ldsV, int wave, int lane, int nd, int ngroups, F&& row_ptr) {
     const int kq = lane >> 4, pos = lane & 15;
@@ -619,7 +625,12 @@ __device__ __attribute__((noinline)) void new_block_path(KernArgAttnK* pk, char*
         for (int j = 0; j < 8; ++j)
             mw[qt][j] = (m < p.M && j < nblk) ? p.mask_bits[((long)bi * p.sq + rrow[qt]) * p.mask_words + j] : 0u;
     }
-    __syncthreads();                                   // keys landed (vmcnt(0) + barrier)
+    // keys landed: every wave drains ITS pieces, then the barrier.  The wait has to be spelled out -- the DMA is inline
+    // assembly, the compiler does not know that loads are pending, and a wave that only waits for its own mask words
+    // behind the barrier reads keys another wave's DMA is still delivering (seen only with thousands of workgroups in
+    // flight: a 64-element batch of append calls; one dispatch round was always fast enough)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (!worker) return;
     const unsigned vbase0 = smem_a + cap * ROWB;
     auto mask_word = [&](int qt, int blk) -> uint32_t {
@@ -1175,6 +1186,7 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const Attn
         if (w < 4) prefix_path_ws<E, true>(p, smem, (int)blockIdx.x - p.has_new, w);
         else prefix_path_ws<E, false>(p, smem, (int)blockIdx.x - p.has_new, w - 4);
     }
+    drain_lds_dma();
 }
 
 // Row blocks 0..rbA-1 carry QTA tiles, the rest QTB: both instantiations execute the same barrier
@@ -1189,6 +1201,7 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_kernel(const AttnK p
         if (rb < p.rbA) partial_entry<E, QTA>(p, smem);
         else partial_entry<E, QTB>(p, smem);
     }
+    drain_lds_dma();
 }
 
 // ---- stage 2: combine + merge ----------------------------------------------------------

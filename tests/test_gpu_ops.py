@@ -427,6 +427,63 @@ def test_full_size_properties_qwq_bf16_32k(ops):
 
 
 # --------------------------------------------------------------------------- #
+# prompt attention (K13): the chunks of a prompt as the batch of one call
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("H,Hkv,L,window,start", [(32, 8, 64 * 9 + 23, -1, 0), (8, 2, 64 * 5, -1, 0), (4, 4, 64 * 3 + 1, 512, 0),
+                                                  (32, 8, 1500, 512, 0), (8, 2, 64 * 4 + 7, -1, 192)])
+def test_prefill_attention_vs_oracle(ops, H, Hkv, L, window, start):
+    """flash_attn_func(causal=True[, window_size=(512,-1)]) + cache fill (llama.py:218, llama_glide.py:227) evaluated as
+    ONE batched call over the prompt's 64-row chunks (+ a ragged tail, + rows that start behind an existing prefix:
+    the sequence-sharded prefill) against the oracle's dense restatement."""
+    gen = torch.Generator(device="cpu").manual_seed(L + H)
+    T = start + L
+    q = torch.randn(1, T, H, 128, generator=gen).to(torch.float16)
+    k = torch.randn(1, T, Hkv, 128, generator=gen).to(torch.float16)
+    v = torch.randn(1, T, Hkv, 128, generator=gen).to(torch.float16)
+    ref = ref_ops.flash_attention(q, k, v, causal=True, window_size=(window, -1))[:, start:]
+    kc = torch.zeros(1, T + 64, Hkv, 128, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    kc[:, :start] = g(k[:, :start])
+    vc[:, :start] = g(v[:, :start])
+    out = ops.prefill_attention(g(q[:, start:]), g(k[:, start:]), g(v[:, start:]), kc, vc, window_left=window, start=start)
+    assert_close_f16(out, ref, atol=2.1e-3, what=f"prefill L={L} start={start}")
+    assert torch.equal(kc[:, :T].cpu(), k) and torch.equal(vc[:, :T].cpu(), v)
+
+
+@pytest.mark.parametrize("n_splits", [0, 2, 11])
+def test_append_attention_large_batch_is_batch_independent(ops, n_splits):
+    """Thousands of workgroups in flight: 64 identical batch elements of an append call (64 new rows behind a 704-key
+    prefix) must all equal the single-element result, run after run.  Regression test of a missing `s_waitcnt vmcnt(0)`
+    in front of the new-key block's barrier (its keys arrive by inline-asm LDS DMA the compiler cannot see): one dispatch
+    round never showed it, this shape failed in most runs."""
+    H, Hkv, s0, n = 32, 8, 704, 64
+    gen = torch.Generator(device="cpu").manual_seed(s0)
+    q = g(torch.randn(1, n, H, 128, generator=gen).to(torch.float16))
+    k = g(torch.randn(1, s0 + n, Hkv, 128, generator=gen).to(torch.float16))
+    v = g(torch.randn(1, s0 + n, Hkv, 128, generator=gen).to(torch.float16))
+    kc = torch.zeros(1, s0 + n + 64, Hkv, 128, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    kc[:, :s0 + n] = k
+    vc[:, :s0 + n] = v
+
+    def call(bsz):
+        lens = torch.full((bsz,), s0, dtype=torch.int32, device=DEV)
+        qq = q.expand(bsz, -1, -1, -1).contiguous()
+        kk = k[:, s0:].expand(bsz, -1, -1, -1).contiguous()
+        vv = v[:, s0:].expand(bsz, -1, -1, -1).contiguous()
+        out = torch.empty_like(qq)
+        d = ops._desc(qq, kc.expand(bsz, -1, -1, -1), vc.expand(bsz, -1, -1, -1), lens, s0 + n, k_new=kk, v_new=vv,
+                      mask_bits=ops.causal_mask_bits(n, DEV).expand(bsz, -1, -1).contiguous(), out=out, new_mode=ops.LS_NEW_FLASH,
+                      n_new=n, scatter_new=0, causal=True, window_left=-1, n_app=n, n_splits=n_splits)
+        ops._run(d, DEV)
+        return out
+    ref = call(1)[0].clone()
+    for _ in range(5):
+        o = call(64)
+        assert (o.float() - ref.float()[None]).abs().max().item() <= 1e-3
+
+
+# --------------------------------------------------------------------------- #
 # BASELINE sizes: the whole hybrid call against the oracle, then size-independent properties
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("L,last_layer", [(16384, False), (131072, False), (131072 - 21, True)])
