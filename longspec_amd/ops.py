@@ -475,10 +475,10 @@ def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: i
     fills ``k_cache/v_cache[:, start:start + L]``.  ``start`` > 0: the rows are positions [start, start + L) of a
     prompt whose first ``start`` rows are already in the caches (sequence-sharded prefill)."""
     b, L, H, D = q.shape
-    CH = PREFILL_CHUNK
+    CH = prefill_chunk(L, H // k.shape[2], window_left, start)
     n_full = L // CH
     if b == 1 and n_full >= 2:
-        return _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start)
+        return _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start, CH)
     outs = []
     for s0 in range(0, L, CH):
         s1 = min(L, s0 + CH)
@@ -488,13 +488,22 @@ def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: i
     return torch.cat(outs, dim=1)
 
 
+def prefill_chunk(L: int, g: int, window_left: int, start: int) -> int:
+    """Prompt rows per chunk.  Long prompts of GQA models (g = H / Hkv >= 4) use g * chunk = 257..320 rows, which puts the
+    prefix part of every chunk on the warp-specialised kernel (ws_eligible: append chunks with kv_len_hint >= 4096); short
+    prompts, windows and small groups keep 64 (the chunking the reference-generated goldens were checked against)."""
+    if window_left < 0 and g >= 4 and start + L >= 8192 and 320 // g >= 32:
+        return 320 // g
+    return PREFILL_CHUNK
+
+
 PREFILL_GROUP = 512       # prompt chunks per launch (bounds the fp32 workspace: 3 x group x 64 rows x H x 512 B)
 PREFILL_SPLITS = 2        # key splits per chunk: with ONE, the ~32 chunks resident at a time walk the same K/V lines in lock
                           # step (measured 0.34 s per layer at 128k against 0.18 s); an ODD count leaves two of the eight XCDs
                           # with the light new-block workgroups only (grid.x = splits + 1, XCD = linear id % 8)
 
 
-def _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start):
+def _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start, CH=PREFILL_CHUNK):
     """The same chunk-wise evaluation with the chunks of a prompt as the BATCH of one call: chunk c is batch element c
     with ``cache_seqlens[c] = start + 64 c`` over the one shared cache (batch stride 0; the prompt's K/V rows are copied
     into it first, so nothing is scattered by the launch), its 64 rows are the appended block with the causal mask.  One
@@ -505,7 +514,6 @@ def _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start):
     _check_qkv(q, k_cache, v_cache)
     b, L, H, D = q.shape
     Hkv = k.shape[2]
-    CH = PREFILL_CHUNK
     n_full = L // CH
     k_cache[:, start:start + L] = k
     v_cache[:, start:start + L] = v

@@ -430,7 +430,8 @@ def test_full_size_properties_qwq_bf16_32k(ops):
 # prompt attention (K13): the chunks of a prompt as the batch of one call
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("H,Hkv,L,window,start", [(32, 8, 64 * 9 + 23, -1, 0), (8, 2, 64 * 5, -1, 0), (4, 4, 64 * 3 + 1, 512, 0),
-                                                  (32, 8, 1500, 512, 0), (8, 2, 64 * 4 + 7, -1, 192)])
+                                                  (32, 8, 1500, 512, 0), (8, 2, 64 * 4 + 7, -1, 192),
+                                                  (8, 2, 8192 + 100, -1, 0)])     # long GQA prompt: 80-row chunks, WS prefix
 def test_prefill_attention_vs_oracle(ops, H, Hkv, L, window, start):
     """flash_attn_func(causal=True[, window_size=(512,-1)]) + cache fill (llama.py:218, llama_glide.py:227) evaluated as
     ONE batched call over the prompt's 64-row chunks (+ a ragged tail, + rows that start behind an existing prefix:
