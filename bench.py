@@ -418,6 +418,7 @@ def main():
             st.use_graphs = graphs
             if graphs:
                 m.prepare_tree_graphs(st)                # one HIP graph per accepted-token count, captured before the clock starts
+            barrier()                                    # no rank polls for a peer that is still capturing
             for _ in range(args.warmup):
                 m.tree_round(st)
             barrier()

@@ -52,14 +52,13 @@ class PeerExchange:
             dist.all_gather_into_tensor(every, mine, group=group)
             _C.check(self.lib.ls_xchg_connect(self._x, bytes(every.cpu().tolist())), "ls_xchg_connect")
         # Ranks that share one GPU (the 2-process tests on a 1-GPU box) keep each other off the CUs while they poll: a
-        # wait can last whole scheduling quanta there.  Give those a long fuse; separate GPUs keep the 1 s default.
+        # wait can last whole scheduling quanta there.  Give those a long fuse.
         ident = [None] * world
         dist.all_gather_object(ident, (os.uname().nodename, str(getattr(torch.cuda.get_device_properties(device), "uuid", device))),
                                group=group)
         self.shared_gpu = len(set(ident)) < world
-        if self.shared_gpu:
-            with torch.cuda.device(device):
-                _C.check(self.lib.ls_xchg_set_timeout(self._x, 60.0), "ls_xchg_set_timeout")
+        with torch.cuda.device(device):            # separate GPUs: 5 s covers a peer that is capturing a graph meanwhile
+            _C.check(self.lib.ls_xchg_set_timeout(self._x, 60.0 if self.shared_gpu else 5.0), "ls_xchg_set_timeout")
         dist.barrier(group=group)                  # nobody pushes before every mailbox is mapped
 
     def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
