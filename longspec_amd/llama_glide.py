@@ -371,10 +371,7 @@ class LlamaGlide(LlamaForCausalLM):
 
     def _chain_generate(self, input_ids, prompt_length, gamma, max_gen_len, eos_id, temperature, drafter):
         assert input_ids is not None, "please give the input"
-        magic = drafter == "magicdec"
-        if temperature > 0 and magic:
-            raise NotImplementedError("magicdec_generate at temperature > 0 (llama_glide.py:854-875) is not implemented; "
-                                      "spec_generate and tree_spec_generate are")
+        magic = drafter == "magicdec"       # (temperature > 0: the same rejection block in both loops, :715-736 = :854-875)
         self._clear_shard()
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"

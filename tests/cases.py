@@ -204,4 +204,5 @@ def chain_stochastic_runs():
         yield dict(name=name, cfg=cfg, target_sd=tgt, draft_sd=drf, prompt=_t(g[f"{name}_prompt"]), wseed=wseed,
                    prompt_len=int(g[f"{name}_prompt_len"]), max_gen_len=int(g[f"{name}_max_gen_len"]),
                    temperature=float(g[f"{name}_temperature"]), torch_seed=int(g[f"{name}_torch_seed"]),
+                   method=str(g[f"{name}_method"]),
                    out=_t(g[f"{name}_out"]), count=int(g[f"{name}_count"]), num=int(g[f"{name}_num"]), family="llama")

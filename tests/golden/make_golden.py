@@ -406,9 +406,10 @@ def gen_chain_stochastic(llama, llama_glide):
     Categorical(p).sample() = multinomial(p, 1) = one exponential_ of shape [b * gamma, V] in the model dtype."""
     arrays = {}
     names = []
-    for name, over, wseed, agree, plen, glen, T in [
-            ("c_mixed", {}, 21, 0.05, 100, 48, 0.7),
-            ("c_gqa", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 23, 0.3, 77, 40, 1.0)]:
+    for name, over, wseed, agree, plen, glen, T, method in [
+            ("c_mixed", {}, 21, 0.05, 100, 48, 0.7, "spec"),
+            ("c_gqa", {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}, 23, 0.3, 77, 40, 1.0, "spec"),
+            ("m_mixed", {}, 25, 0.3, 1070, 32, 0.9, "magicdec")]:       # the MagicDec baseline shares the block (:854-875)
         cfg = toy.toy_config(**over)
         tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
         m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
@@ -416,14 +417,15 @@ def gen_chain_stochastic(llama, llama_glide):
         pl = torch.tensor([plen])
         torch.manual_seed(9000 + wseed)
         with torch.inference_mode():
-            out, count, num, _, _ = m.spec_generate(ids, pl, gamma=4, max_gen_len=glen, temperature=T)
-        print(f"[{name}] T={T} count={int(count)} num={int(num)} out={out[0, :12].tolist()}")
+            fn = m.magicdec_generate if method == "magicdec" else m.spec_generate
+            out, count, num, _, _ = fn(ids, pl, gamma=4, max_gen_len=glen, temperature=T)
+        print(f"[{name}] {method} T={T} count={int(count)} num={int(num)} out={out[0, :12].tolist()}")
         names.append(name)
         arrays.update({
             f"{name}_cfg_keys": np.array(sorted(over.keys()), dtype="U32"),
             f"{name}_cfg_vals": np.array([over[k] for k in sorted(over.keys())], dtype=np.int64),
             f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
-            f"{name}_temperature": T, f"{name}_torch_seed": 9000 + wseed,
+            f"{name}_temperature": T, f"{name}_torch_seed": 9000 + wseed, f"{name}_method": np.array(method, dtype="U16"),
             f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
             f"{name}_prompt": ids, f"{name}_out": out, f"{name}_count": int(count), f"{name}_num": int(num),
         })

@@ -162,7 +162,8 @@ def test_spec_generate_with_temperature_matches_reference(run):
     ops.stochastic_chain_noise_fn = lambda shape, dtype, device: torch.empty(shape, dtype=dtype).exponential_(1).to(device)
     try:
         torch.manual_seed(run["torch_seed"])
-        out, count, num, _, _ = m.spec_generate(run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"), gamma=4,
+        fn = m.magicdec_generate if run["method"] == "magicdec" else m.spec_generate
+        out, count, num, _, _ = fn(run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"), gamma=4,
                                                 max_gen_len=run["max_gen_len"], temperature=run["temperature"])
     finally:
         ops.stochastic_uniform_fn = None

@@ -85,7 +85,8 @@ def test_tree_spec_generate_matches_reference(run):
 @pytest.mark.parametrize("run", RUNS, ids=lambda r: r["name"])
 def test_chain_spec_generate_matches_reference(run):
     m = build(run)
-    out, count, num, _, _ = m.spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
+    fn = m.magicdec_generate if run["method"] == "magicdec" else m.spec_generate
+    out, count, num, _, _ = fn(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
                                             max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
     assert (int(count), int(num)) == (run["chain_count"], run["chain_num"])
     n = min(int(count) + int(num), run["max_gen_len"])
@@ -161,7 +162,8 @@ def test_spec_generate_with_temperature_matches_reference(run):
     host loop draws from torch's global generator in the reference's order (oracle/ref_ops.py::chain_accept_stochastic)."""
     m = build(run)
     torch.manual_seed(run["torch_seed"])
-    out, count, num, _, _ = m.spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
+    fn = m.magicdec_generate if run["method"] == "magicdec" else m.spec_generate
+    out, count, num, _, _ = fn(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
                                             max_gen_len=run["max_gen_len"], temperature=run["temperature"])
     assert (int(count), int(num)) == (run["count"], run["num"])
     assert torch.equal(out, run["out"])
