@@ -85,8 +85,7 @@ def test_tree_spec_generate_matches_reference(run):
 @pytest.mark.parametrize("run", RUNS, ids=lambda r: r["name"])
 def test_chain_spec_generate_matches_reference(run):
     m = build(run)
-    fn = m.magicdec_generate if run["method"] == "magicdec" else m.spec_generate
-    out, count, num, _, _ = fn(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
+    out, count, num, _, _ = m.spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), gamma=4,
                                             max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
     assert (int(count), int(num)) == (run["chain_count"], run["chain_num"])
     n = min(int(count) + int(num), run["max_gen_len"])
