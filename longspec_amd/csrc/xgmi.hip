@@ -127,7 +127,14 @@ int ls_xchg_connect(ls_xchg* x, const void* handles) {
         memcpy(&h, static_cast<const char*>(handles) + (size_t)r * LS_XCHG_HANDLE_BYTES, sizeof(h));
         void* p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) LS_FAIL(LS_ERR_LAUNCH, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            for (int q = 0; q < r; ++q)            // nothing half-mapped is left behind
+                if (q != x->rank && x->peers[q]) {
+                    (void)hipIpcCloseMemHandle(x->peers[q]);
+                    x->peers[q] = nullptr;
+                }
+            LS_FAIL(LS_ERR_LAUNCH, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+        }
         x->peers[r] = static_cast<char*>(p);
     }
     hipError_t e = hipMemcpy(x->peers_dev, x->peers, sizeof(char*) * XCHG_MAX_WORLD, hipMemcpyHostToDevice);
