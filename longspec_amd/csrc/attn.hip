@@ -926,7 +926,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) qf[qt][k4] = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
         }
-        float mref[QT], lsum[QT];
+        float mref[QT];
         auto mask_tail = [&](f32x4 (&s)[2][QT], int b) {    // keys >= L of a block that crosses the end of the cache
             const int ka0 = (b_begin + b) * 32;
             if (ka0 + 32 > L) {
@@ -948,13 +948,10 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             }
         };
         // mode 0: reference from the first 64 keys, fixed;  1: QK-only pass for the true row maxima;  2: as 0 with mref given
-        auto run_pass = [&](int mode) -> float {
-            float pmax = 0.f;
+        auto run_pass = [&](int mode) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                lsum[qt] = 0.f;
+            for (int qt = 0; qt < QT; ++qt)
                 if (mode != 2) mref[qt] = -INFINITY;
-            }
             pass_head();
             f32x4 s_cur[2][QT];
             if (mode == 0 && nblocks > 1) {        // block 1's share of the reference (block 0's follows)
@@ -969,23 +966,20 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             }
             __builtin_amdgcn_s_barrier();          // K(0) is consumed: step 0 may overwrite its slot
             typedef __attribute__((address_space(3))) typename E::V8 lds_v8;
-            // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS; row sums; overflow watch
+            // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS.  The row sums are NOT formed here: the
+            // O wave gets them from the matrix pipe (a ninth V^T tile whose row 0 is all ones: l = sum of the fp16 P it
+            // multiplies -- the normaliser of exactly the numerators used), which takes 40 adds and the overflow watch off
+            // this wave's critical VALU path; a P that overflowed fp16 shows up there as a non-finite l and redoes the split
             auto softmax_store = [&](int j) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     const float mc = mref[qt] * c;
-                    float ps = 0.f;
                     typename E::V8 pf;
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc));
-                            ps += pe;
-                            pf[kt * 4 + e] = E::from_f32(pe);
-                        }
-                    lsum[qt] += ps;
-                    pmax = fmaxf(pmax, ps);                // sum of 8 probabilities: a conservative stand-in for their max
+                        for (int e = 0; e < 4; ++e)
+                            pf[kt * 4 + e] = E::from_f32(__builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc)));
                     *(lds_v8*)(uintptr_t)(p_base + (j & 1) * WS_PBUF_B + qt * 1024) = pf;
                 }
             };
@@ -1052,13 +1046,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 step_head(nblocks);                        // the O waves' last P.V
                 step_tail(nblocks);
             }
-            return pmax;
         };
-        const float pmax = run_pass(0);
+        run_pass(0);
         if (tid == 0) *redo_flag = 0;
         __syncthreads();
-        if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;         // fp16 tops out at 65504
-        __syncthreads();
+        __syncthreads();                                   // (the O waves raise the flag in between)
         if (*redo_flag) {
             __syncthreads();
             run_pass(1);
@@ -1069,29 +1061,24 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             reinterpret_cast<unsigned long long*>(p.new_o)[lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
                                                                    prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
 #endif
-        // row sums and the log-normaliser; the O wave of the pair scales its accumulators by 1/l
+        // the reference of every row, for the O wave's log-normaliser lse = m*scale + ln(l)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float lt = wave_xor_sum_16_32(lsum[qt]);
-            const float inv = lt > 0.f ? 1.f / lt : 0.f;
-            const float lse = lt > 0.f ? mref[qt] * p.scale + __logf(lt) : -INFINITY;
-            const int m = row0 + qt * 16 + l15;
-            if (g4 == 0) {
-                s_inv[pair * 80 + qt * 16 + l15] = inv;
-                if (m < p.M) {
-                    const int head = kvh * p.g + m / p.sq;
-                    p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow[qt]] = lse;
-                }
-            }
-        }
+        for (int qt = 0; qt < QT; ++qt)
+            if (g4 == 0) s_inv[pair * 80 + qt * 16 + l15] = mref[qt] * p.scale;
         __syncthreads();
     } else {
         f32x4 acc[8][QT];
+        f32x4 lacc[QT];                            // row 0 of the ones tile: l of query row l15 in the lanes with g4 == 0, element 0
+        typename E::V8 ones;                       // A operand of that tile: row 0 (lanes with l15 == 0) = 1 for every key
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = E::from_f32(l15 == 0 ? 1.f : 0.f);
         auto run_pass = [&](int mode) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
+            for (int qt = 0; qt < QT; ++qt) {
+                lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             pass_head();
             __builtin_amdgcn_s_barrier();          // the S waves' look at blocks 0 and 1 is over
 #pragma unroll 1
@@ -1122,6 +1109,8 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
                 }
                 WS_TS(1);
                 // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
@@ -1136,6 +1125,12 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         };
         run_pass(0);
         __syncthreads();
+        {   // an fp16 P that overflowed (or an inf - inf behind it) leaves a non-finite row sum: redo with the true row maxima
+            bool bad = false;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lacc[qt][0]) <= 3.0e38f);
+            if (__any(bad && g4 == 0) && lane == 0) *redo_flag = 1;
+        }
         __syncthreads();
         if (*redo_flag) {
             __syncthreads();
@@ -1147,13 +1142,17 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             reinterpret_cast<unsigned long long*>(p.new_o)[8 + lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
                                                                        prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
 #endif
-        __syncthreads();                           // the pair's 1/l is in LDS
+        __syncthreads();                           // the pair's m*scale is in LDS
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            const float inv = s_inv[pair * 80 + qt * 16 + l15];
+            const float lt = __shfl(lacc[qt][0], l15);       // (lanes g4 == 0 hold it)
+            const float inv = lt > 0.f ? 1.f / lt : 0.f;
             const int m = row0 + qt * 16 + l15;
             if (m < p.M) {
                 const int head = kvh * p.g + m / p.sq;
+                if (g4 == 0)
+                    p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow[qt]] =
+                        lt > 0.f ? s_inv[pair * 80 + qt * 16 + l15] + __logf(lt) : -INFINITY;
                 float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
