@@ -970,7 +970,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             // O wave gets them from the matrix pipe (a ninth V^T tile whose row 0 is all ones: l = sum of the fp16 P it
             // multiplies -- the normaliser of exactly the numerators used), which takes 40 adds and the overflow watch off
             // this wave's critical VALU path; a P that overflowed fp16 shows up there as a non-finite l and redoes the split
-            auto softmax_store = [&](int j) {
+            auto softmax_store = [&](int j, const f32x4 (&sc)[2][QT]) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     const float mc = mref[qt] * c;
@@ -979,7 +979,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            pf[kt * 4 + e] = E::from_f32(__builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc)));
+                            pf[kt * 4 + e] = E::from_f32(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][qt][e], c, -mc)));
                     *(lds_v8*)(uintptr_t)(p_base + (j & 1) * WS_PBUF_B + qt * 1024) = pf;
                 }
             };
@@ -999,13 +999,12 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             } else {
                 // steady state: ONE basic block holds the QK^T MFMAs of block j+1 and the VALU work of block j, so that
                 // the scheduler can lay them out as asked below: an MFMA, then the VALU instructions its 16 cycles hide
-                auto steady_step = [&](int j, auto masked, auto fixed_wait) {
+                auto step_ab = [&](int j, f32x4 (&s_in)[2][QT], f32x4 (&s_next)[2][QT], auto masked, auto fixed_wait) {
                     WS_T0();
                     step_head(j);
                     WS_TS(0);
-                    f32x4 s_next[2][QT];
                     qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
-                    softmax_store(j);
+                    softmax_store(j, s_in);
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all 8 K-fragment LDS reads first,
                     __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);            // VALU work while they are in flight
 #pragma unroll
@@ -1014,10 +1013,6 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);         // 6 VALU
                     }
                     if constexpr (decltype(masked)::value) mask_tail(s_next, j + 1);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) s_cur[kt][qt] = s_next[kt][qt];
                     WS_TS(1);
                     // K(j+2) is multiplied at step j+1.  In the steady state exactly LA-1 younger blocks (2 pieces each) are in
                     // flight: one immediate wait instead of the compare / branch ladder of wait_block (measured: 155-170 ns of
@@ -1032,15 +1027,34 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 };
                 // only the split's LAST block can cross the end of the cache: its masking (35 selects per lane when the
                 // compiler if-converts it into every iteration) is peeled off the loop
+                // one step with the scores copied back (edges of the loop), and the steady loop two steps at a time with the two
+                // score register sets swapping roles -- no 40-register copy per step
+                auto steady_step = [&](int j, auto masked, auto fixed_wait) {
+                    f32x4 s_next[2][QT];
+                    step_ab(j, s_cur, s_next, masked, fixed_wait);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) s_cur[kt][qt] = s_next[kt][qt];
+                };
                 const int n_fixed = max(0, nblocks - 1 - WS_LA);      // steps j with j + 2 + LA <= nblocks
+                int j0 = 0;
+                {
+                    f32x4 s_alt[2][QT];
 #pragma unroll 1
-                for (int j = 0; j < n_fixed; ++j) steady_step(j, std::false_type{}, std::true_type{});
+                    for (; j0 + 2 <= n_fixed; j0 += 2) {
+                        step_ab(j0, s_cur, s_alt, std::false_type{}, std::true_type{});
+                        step_ab(j0 + 1, s_alt, s_cur, std::false_type{}, std::true_type{});
+                    }
+                }
+#pragma unroll 1
+                for (int j = j0; j < n_fixed; ++j) steady_step(j, std::false_type{}, std::true_type{});
 #pragma unroll 1
                 for (int j = n_fixed; j + 2 < nblocks; ++j) steady_step(j, std::false_type{}, std::false_type{});
                 if (nblocks > 1) steady_step(nblocks - 2, std::true_type{}, std::false_type{});
                 if (nblocks > 0) {                         // last block: nothing left to multiply
                     step_head(nblocks - 1);
-                    softmax_store(nblocks - 1);
+                    softmax_store(nblocks - 1, s_cur);
                     step_tail(nblocks - 1);
                 }
                 step_head(nblocks);                        // the O waves' last P.V
