@@ -4,6 +4,8 @@
 //   S patterns: 0 = 40 MFMAs, then the VALU block      1 = (1 MFMA, 1 fma, 1 exp, 2 add) x 40
 //               2 = VALU only                           3 = MFMAs only
 //               4 = (2 MFMAs, 2 fma, 2 exp, 4 add) x 20 5 = (4 MFMAs, then 16 VALU) x 10
+//               6 / 7 = patterns 0 / 1 with the CURRENT mix of the kernel (row sums on the matrix pipe): 40 fma, 40 exp,
+//                       20 packed conversions, no adds; the O wave then issues 45 MFMAs per step (O pattern 3)
 //   O patterns: 0 = absent (4 waves per workgroup)      1 = 40 MFMAs per step        2 = idle wave
 //   hipcc --offload-arch=gfx950 -O3 tools/mb/s_wave.hip -o s_wave && ./s_wave
 #include <hip/hip_runtime.h>
@@ -24,6 +26,7 @@ __device__ inline f16x8 rnd(unsigned s) {
 #define FMA(d, x, c, m) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(c), "v"(m))
 #define EXP(d, x) asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(x))
 #define ADD(d, x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(x))
+#define CVT(d, x, y) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
 
 template <int SP, int OP>
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
@@ -60,6 +63,18 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
                     FMA(t[i], x[i], c, m); FMA(t[i + 1], x[i + 1], c, m); EXP(e[i], t[i]); EXP(e[i + 1], t[i + 1]);
                     ADD(sum0, e[i]); ADD(sum1, e[i + 1]); ADD(sum0, e[i]); ADD(sum1, e[i + 1]);
                 }
+            } else if constexpr (SP == 6) {
+                unsigned pk[20];
+#pragma unroll
+                for (int i = 0; i < 40; ++i) MFMA(acc[i % 10], a[i / 10], b[i % 5]);
+#pragma unroll
+                for (int i = 0; i < 40; ++i) { FMA(t[i], x[i], c, m); EXP(e[i], t[i]); if (i & 1) { CVT(pk[i / 2], e[i - 1], e[i]); } }
+                sum0 += __uint_as_float(pk[it % 20]) * 0.f;
+            } else if constexpr (SP == 7) {
+                unsigned pk[20];
+#pragma unroll
+                for (int i = 0; i < 40; ++i) { MFMA(acc[i % 10], a[i / 10], b[i % 5]); FMA(t[i], x[i], c, m); EXP(e[i], t[i]); if (i & 1) { CVT(pk[i / 2], e[i - 1], e[i]); } }
+                sum0 += __uint_as_float(pk[it % 20]) * 0.f;
             } else {
 #pragma unroll
                 for (int i = 0; i < 40; i += 4) {
@@ -71,10 +86,10 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
             }
         }
         s = sum0 + sum1;
-    } else if constexpr (OP == 1) {
+    } else if constexpr (OP == 1 || OP == 3) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int i = 0; i < 40; ++i) MFMA(acc[i % 10], a[i / 10], b[i % 5]);
+            for (int i = 0; i < (OP == 3 ? 45 : 40); ++i) MFMA(acc[i % 10], a[(i / 10) & 3], b[i % 5]);
         }
     }
     for (int i = 0; i < 10; ++i) s += acc[i][0] + acc[i][3];
@@ -114,5 +129,8 @@ int main() {
     run<1, 1>("S: (1 MFMA + 4 VALU) x 40       O: 40 MFMA");
     run<4, 1>("S: (2 MFMA + 8 VALU) x 20       O: 40 MFMA");
     run<5, 1>("S: (4 MFMA + 16 VALU) x 10      O: 40 MFMA");
+    run<6, 0>("S: 40 MFMA then VALU (100: no adds) O: absent");
+    run<6, 3>("S: 40 MFMA then VALU (100: no adds) O: 45 MFMA");
+    run<7, 3>("S: (1 MFMA + 2.5 VALU) x 40      O: 45 MFMA");
     return 0;
 }
