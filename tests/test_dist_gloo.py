@@ -102,3 +102,34 @@ def test_sequence_sharded_prefill_and_decode_match_single_process(world, run_nam
     for rank, out, count, num in res:
         assert torch.equal(out, run["tree_out"]), f"rank {rank}: token ids differ from the single-process reference"
         assert (count, num) == (run["tree_count"], run["tree_num"])
+
+
+def _peer_fallback_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from longspec_amd.dist import KVShard
+    sh = KVShard(rank, world, shard_rows=16)
+    ok = sh.enable_peer_exchange(1024, torch.device("cpu"))        # no GPU here: must decline, loudly, and keep working
+    send, recv = sh.buffers(10, torch.device("cpu"))
+    send.fill_(float(rank + 1))
+    out = sh.exchange(send, recv).clone()
+    q.put((rank, ok, sh.graph_safe, sh.peer_tried, out[:, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_declines_without_a_gpu_and_the_collective_carries_on():
+    """`KVShard.enable_peer_exchange` where the IPC mailboxes cannot exist (this CPU suite): returns False, leaves
+    `graph_safe` off and the shard on the torch.distributed all-gather -- never a silent half-state."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=30) for p in procs]
+    for rank, ok, safe, tried, col in res:
+        assert ok is False and safe is False and tried is True
+        assert col == [1.0, 2.0]
