@@ -57,6 +57,20 @@ MODELS = {
 }
 TREE = [4, 16, 16, 16, 16]
 
+# BASELINE.json "configs", verbatim, and what each means for this script (prefix_per_gpu applies at --gpus 1)
+BASELINE_CONFIGS = [
+    dict(name="Vicuna-7B-v1.5-16k + longspec draft, tree_shape 4 16 16 16 16, 4k-token synthetic prefix, temperature 0, CPU reference path (plumbing, no GPU)",
+         model="vicuna-7b-16k", prefix_total=4096, prefix_per_gpu=4096),
+    dict(name="Llama-3-8B-Instruct-262k + longspec draft, 16k synthetic prefix, tree_shape 4 16 16 16 16, 1\u00d7MI355X",
+         model="llama3-8b-262k", prefix_total=16384, prefix_per_gpu=16384),
+    dict(name="Llama-3-8B-Instruct-262k, 128k synthetic prefix, KV sequence-sharded across 8\u00d7MI355X with RCCL over xGMI",
+         model="llama3-8b-262k", prefix_total=131072, prefix_per_gpu=0),
+    dict(name="LongChat-13B-16k, GovReport-length (\u22488k) prefixes, chain vs tree method A/B on 1\u00d7MI355X",
+         model="longchat-13b-16k", prefix_total=8192, prefix_per_gpu=8192),
+    dict(name="QwQ-32B-Preview + longspec draft, 20k-token long-CoT generation, 32k prefix, bf16, 2\u00d7MI355X KV shard",
+         model="qwq-32b", prefix_total=32768, prefix_per_gpu=0),
+]
+
 
 def make_config(name):
     d = dict(MODELS[name])
@@ -307,12 +321,46 @@ def main():
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
                          "with one rank, to price its extra launches without a second GPU")
+    ap.add_argument("--config", type=int, default=None, choices=range(len(BASELINE_CONFIGS)),
+                    help="one of BASELINE.json's configs by index: sets the model / prefix / dtype and names the config verbatim in "
+                         "config.workload (configs[2] is the default workload; 0 runs the Vicuna-7B 4k case on the GPU)")
     args = ap.parse_args()
+    if args.config is not None:
+        preset = BASELINE_CONFIGS[args.config]
+        args.model = preset["model"]
+        if preset.get("prefix_per_gpu") and args.gpus == 1:
+            args.prefix_per_gpu = preset["prefix_per_gpu"]
+        else:
+            args.prefix_total, args.prefix_per_gpu = preset["prefix_total"], 0
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rendezvous on
+        # 127.0.0.1 at a free port.  Rank 0's JSON line stays the last line of stdout (the children inherit it).
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("LS_BENCH_DRY_RUN"):
+        # launcher test (tests/test_bench_launcher.py, no GPU): the ranks rendezvous over gloo, rank 0 prints the line's skeleton
+        dist.init_process_group("gloo")
+        seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if args.share_gpu:
         local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL, hipIpc mailboxes): before the runtime starts
@@ -474,7 +522,8 @@ def main():
         "unit": "accepted tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
         "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix "
+        "config": {"workload": (BASELINE_CONFIGS[args.config]["name"] + " -- " if args.config is not None else "") +
+                               f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix "
                                f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1"
                                + ("" if weak or args.model != "llama3-8b-262k" or L_total != 131072 else
                                   " [BASELINE.json metric config: Llama-3-8B @128k ctx]"),
@@ -484,6 +533,9 @@ def main():
         "hip_graphs": bool(graphs and st.graphs is not False),
     }
     if world > 1 or args.shard_path:
+        out["backend"] = dist.get_backend()
+        if out["backend"] == "nccl":
+            out["rccl_ranks"] = dist.get_world_size()        # what RCCL itself saw
         out["exchange"] = ("peer stores into IPC-mapped mailboxes, fused into the two combine kernels of the call (csrc/xgmi.hip)" if shard.peer is not None
                            else "torch.distributed all-gather per attention call")
         if exchange_note:

@@ -28,7 +28,7 @@ DRAFT_TENSORS = (
 
 
 def load_config(path: str) -> SimpleNamespace:
-    path = resolve_path(path)
+    path = resolve_path(path, need_tensors=False)
     with open(os.path.join(path, "config.json")) as f:
         d = json.load(f)
     d.setdefault("head_dim", d["hidden_size"] // d["num_attention_heads"])
@@ -40,7 +40,14 @@ def load_config(path: str) -> SimpleNamespace:
     return SimpleNamespace(**d)
 
 
-def resolve_path(path_or_id: str) -> str:
+def _snapshot_complete(path: str) -> bool:
+    try:
+        return bool(checkpoint_files(path))
+    except FileNotFoundError:                    # an index that names absent shards
+        return False
+
+
+def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
     """A local checkpoint directory / file as is; anything else is taken as a Hugging Face hub id
     (``lmsys/vicuna-7b-v1.5-16k``, ``sail/longspec-vicuna-7b-v1.5-16k`` ... -- what
     ``inference_long-bench.py:41-62`` passes to ``from_pretrained``) and resolved through the local HF cache first,
@@ -52,16 +59,24 @@ def resolve_path(path_or_id: str) -> str:
     except ImportError as e:                     # pragma: no cover
         raise FileNotFoundError(f"{path_or_id!r} is not a local path and huggingface_hub is not installed") from e
     patterns = ["*.json", "*.safetensors", "*.bin", "*.pth", "*.pt", "*.model"]
+    cached = None
     try:
-        return snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns)
+        cached = snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns)
+        # A snapshot can be PARTIAL: `AutoConfig.from_pretrained(hub_id)` (inference_long-bench.py:104) caches config.json alone,
+        # and the local-only pass cannot tell (no tree listing is cached).  Only a snapshot that holds its tensors -- every shard
+        # its index names -- is complete; anything else goes on to the networked pass, which fetches what is missing.
+        if _snapshot_complete(cached):
+            return cached
     except Exception:
         pass
     try:
         return snapshot_download(path_or_id, allow_patterns=patterns)
     except Exception as e:
+        if cached is not None and os.path.exists(os.path.join(cached, "config.json")) and not need_tensors:
+            return cached                        # config-only consumers (load_config) can live with the partial snapshot
         raise FileNotFoundError(
             f"{path_or_id!r} is neither a local checkpoint path nor a hub repository reachable from this machine "
-            f"(not in the HF cache, download failed: {type(e).__name__}).  Download it once "
+            f"({'only a partial snapshot (no tensors) is' if cached else 'not'} in the HF cache, download failed: {type(e).__name__}).  Download it once "
             f"(`huggingface-cli download {path_or_id}`) or pass a local directory.") from e
 
 

@@ -42,24 +42,57 @@ class PeerExchange:
         self.rank, self.world, self.group, self.device = rank, world, group, device
         self.cap = (int(cap_floats) + 3) // 4 * 4
         self._x = C.c_void_p()
-        with torch.cuda.device(device):
-            _C.check(self.lib.ls_xchg_create(rank, world, self.cap, C.byref(self._x)), "ls_xchg_create")
-            h = (C.c_ubyte * 64)()
-            _C.check(self.lib.ls_xchg_handle(self._x, h), "ls_xchg_handle")
-            on = device if dist.get_backend(group) == "nccl" else "cpu"
-            mine = torch.tensor(list(bytes(h)), dtype=torch.uint8, device=on)
-            every = torch.empty(world * 64, dtype=torch.uint8, device=on)
-            dist.all_gather_into_tensor(every, mine, group=group)
-            _C.check(self.lib.ls_xchg_connect(self._x, bytes(every.cpu().tolist())), "ls_xchg_connect")
+        on = device if dist.get_backend(group) == "nccl" else "cpu"
+        self._on = on
+
+        # Construction is a SEQUENCE of collectives with local steps in between that can fail on one rank only (out of memory
+        # in ls_xchg_create, hipIpcOpenMemHandle in ls_xchg_connect ...).  A rank that raised out of the sequence on its own
+        # would leave its peers blocked in the next collective, so every local step reports a status, the ranks agree on it
+        # (all-reduce MIN) BEFORE the next collective, and on any rank's failure all of them close and raise together.
+        def step(what, fn):
+            err = None
+            try:
+                fn()
+            except Exception as e:                  # noqa: BLE001
+                err = e
+            self._agree(err is None, what, err)
+
+        def create():
+            with torch.cuda.device(device):
+                _C.check(self.lib.ls_xchg_create(rank, world, self.cap, C.byref(self._x)), "ls_xchg_create")
+                self._h = (C.c_ubyte * 64)()
+                _C.check(self.lib.ls_xchg_handle(self._x, self._h), "ls_xchg_handle")
+
+        step("create", create)
+        mine = torch.tensor(list(bytes(self._h)), dtype=torch.uint8, device=on)
+        every = torch.empty(world * 64, dtype=torch.uint8, device=on)
+        dist.all_gather_into_tensor(every, mine, group=group)
+
+        def connect():
+            with torch.cuda.device(device):
+                _C.check(self.lib.ls_xchg_connect(self._x, bytes(every.cpu().tolist())), "ls_xchg_connect")
+
+        step("connect", connect)
         # Ranks that share one GPU (the 2-process tests on a 1-GPU box) keep each other off the CUs while they poll: a
         # wait can last whole scheduling quanta there.  Give those a long fuse.
         ident = [None] * world
         dist.all_gather_object(ident, (os.uname().nodename, str(getattr(torch.cuda.get_device_properties(device), "uuid", device))),
                                group=group)
         self.shared_gpu = len(set(ident)) < world
-        with torch.cuda.device(device):            # separate GPUs: 5 s covers a peer that is capturing a graph meanwhile
-            _C.check(self.lib.ls_xchg_set_timeout(self._x, 60.0 if self.shared_gpu else 5.0), "ls_xchg_set_timeout")
-        dist.barrier(group=group)                  # nobody pushes before every mailbox is mapped
+
+        def fuse():
+            with torch.cuda.device(device):        # separate GPUs: 5 s covers a peer that is capturing a graph meanwhile
+                _C.check(self.lib.ls_xchg_set_timeout(self._x, 60.0 if self.shared_gpu else 5.0), "ls_xchg_set_timeout")
+
+        step("set_timeout", fuse)                  # (its all-reduce is also the barrier: nobody pushes before every mailbox is mapped)
+
+    def _agree(self, ok: bool, what: str, err=None):
+        """All ranks learn whether `what` worked EVERYWHERE; if not, every rank closes its half and raises."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._on)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if not int(flag.item()):
+            self.close()
+            raise RuntimeError(f"peer exchange: {what} failed on " + (f"this rank ({err})" if not ok else "another rank"))
 
     def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
         """recv [world, stride] <- every rank's ``send`` (fp32, numel a multiple of 4, <= cap).  Current stream, no host sync."""
@@ -87,7 +120,7 @@ class PeerExchange:
             dist.all_gather_into_tensor(ref.view(-1), send, group=self.group)
             ok = ok and bool(torch.equal(got, ref))
         ok = ok and not self.status()[1]
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._on)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(int(flag.item()))
 
@@ -126,18 +159,32 @@ class KVShard:
         if self.peer is not None:
             self.peer.close()
             self.peer = None
+        # every way out of this block is taken by ALL ranks together: PeerExchange() agrees on each of its local steps and
+        # raises everywhere or nowhere, self_check() returns one all-reduced verdict -- so `self.peer` (and with it the
+        # path KVShard.attend takes) is the same on every rank
         try:
             peer = PeerExchange(self.rank, self.world, cap_floats, device, self.group)
-            if peer.self_check():
-                self.peer = peer
-            else:
-                peer.close()
-                print(f"[longspec_amd.dist] rank {self.rank}: peer-store exchange failed its self-check; "
-                      "using the torch.distributed all-gather", file=sys.stderr, flush=True)
-        except Exception as e:                      # noqa: BLE001 -- IPC not available on this system
+        except RuntimeError as e:                   # IPC not available on this system (agreed by all ranks)
             print(f"[longspec_amd.dist] rank {self.rank}: peer-store exchange unavailable ({e}); "
                   "using the torch.distributed all-gather", file=sys.stderr, flush=True)
+            return False
+        if peer.self_check():
+            self.peer = peer
+        else:
+            peer.close()
+            print(f"[longspec_amd.dist] rank {self.rank}: peer-store exchange failed its self-check; "
+                  "using the torch.distributed all-gather", file=sys.stderr, flush=True)
         return self.peer is not None
+
+    def raise_if_exchange_failed(self):
+        """Reads the peer exchange's timeout latch (one device synchronisation).  Once a wait has given up, every later
+        attention call merged whatever was in the mailboxes: the generation is void and says so."""
+        if self.peer is None:
+            return
+        done, timed_out = self.peer.status()
+        if timed_out:
+            raise RuntimeError(f"rank {self.rank}: a peer-exchange wait timed out (after {done} exchanges): a peer is slow or gone; "
+                               "the tokens generated since then are invalid")
 
     @property
     def graph_safe(self) -> bool:

@@ -254,7 +254,8 @@ class LlamaAttention(nn.Module):
         """Prefill of this rank's slice of the prompt: ``hidden_states`` are the local rows
         [lo, lo + n).  Every rank's K/V rows of the layer are all-gathered into a scratch cache laid out by global row, and
         the local rows are appended onto rows [0, lo) of it with the SAME causal block-wise calls the single-GPU prefill
-        makes for those rows (same lengths, same grid bounds -- so the same numbers).  What stays is the local shard:
+        makes for those rows (chunk size from the whole prompt, boundaries at global multiples of it: the same numbers for
+        every chunk a shard boundary does not cut).  What stays is the local shard:
         K_Cache/V_Cache = [local rows | room for the tail], exactly what ``dist.shard_model_kv`` leaves behind."""
         sh = self.shard
         lo, n, P = sh.prefill_ctx
@@ -267,7 +268,7 @@ class LlamaAttention(nn.Module):
         # [W, bsz, Ls, Hkv, D] -> [bsz, W*Ls, Hkv, D]: global row = rank * Ls + i (every rank before the tail is full)
         all_k = sh.gather_rows(pad_k).permute(1, 0, 2, 3, 4).reshape(bsz, sh.world * sh.Ls, Hkv, D)
         all_v = sh.gather_rows(pad_v).permute(1, 0, 2, 3, 4).reshape(bsz, sh.world * sh.Ls, Hkv, D)
-        attn = self.ops.prefill_attention(q, k, v, all_k, all_v, start=lo)
+        attn = self.ops.prefill_attention(q, k, v, all_k, all_v, start=lo, total=P)
         rows = (n if sh.is_tail else sh.Ls) + self.max_len
         self.K_Cache = q.new_zeros((bsz, rows, Hkv, D))
         self.V_Cache = q.new_zeros((bsz, rows, Hkv, D))

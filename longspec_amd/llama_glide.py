@@ -243,7 +243,6 @@ class LlamaGlide(LlamaForCausalLM):
         return attn.K_Cache, attn.V_Cache
 
     # ------------------------------------------------------------------------------------------
-    @torch.inference_mode()
     def _clear_shard(self):
         """A shard set by an earlier ``tree_spec_generate(shard=...)`` on this object must not leak into loops that
         prefill a full, unsharded cache."""
@@ -251,6 +250,7 @@ class LlamaGlide(LlamaForCausalLM):
             layer.self_attn.shard = None
         self.glide.cross_attn.shard = None
 
+    @torch.inference_mode()
     def vanilla_generate(self, input_ids, prompt_length, max_gen_len=64, eos_id=151645):       # :552-585
         assert input_ids is not None, "please give the input"
         self._clear_shard()
@@ -519,8 +519,15 @@ class LlamaGlide(LlamaForCausalLM):
         for out_index in range(1, max_gen_len):
             if not (self.tree_round_stochastic(st) if temperature > 0 else self.tree_round(st)):
                 break
+            if shard is not None and out_index % 32 == 0:
+                shard.raise_if_exchange_failed()
         _sync(input_ids)
         elapsed_time = time.time() - start_time
+        if shard is not None:
+            # a wait that gave up latches the exchange's error flag and every later wait returns at once: the rounds since
+            # then merged stale mailbox records.  Never hand such tokens back (the peers fail the same way: a rank that
+            # raises stops pushing, and their next wait times out)
+            shard.raise_if_exchange_failed()
         return st.output_ids, st.count, st.num, elapsed_time, st.spec_mask
 
     def _sharded_prefill(self, input_ids, input_len, position_ids, shard):

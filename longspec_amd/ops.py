@@ -467,20 +467,29 @@ def kvcache_attention(q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, c
 PREFILL_CHUNK = 64
 
 
-def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: int = 0):
+def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: int = 0, total: Optional[int] = None):
     """Prompt attention (K13) through the decode kernels: the prompt is appended to the (empty)
     caches ``PREFILL_CHUNK`` rows at a time with the causal(+window) append form of
     ``kvcache_attention`` -- the same function as ``flash_attn_func(causal=True[, window])``
     (``llama.py:218``, ``llama_glide.py:227``), evaluated block-wise.  [b,L,H,128] -> [b,L,H,128];
     fills ``k_cache/v_cache[:, start:start + L]``.  ``start`` > 0: the rows are positions [start, start + L) of a
-    prompt whose first ``start`` rows are already in the caches (sequence-sharded prefill)."""
+    prompt of ``total`` rows whose first ``start`` rows are already in the caches (sequence-sharded prefill).  The chunk
+    size follows from the WHOLE prompt and chunk boundaries sit at multiples of it counted from global row 0, so a rank
+    of a sharded prefill makes the very calls the single-GPU prefill makes for its rows -- except for the one chunk a shard
+    boundary cuts in two (<= chunk rows per boundary: same function, other block split, equal within the fp16 tolerance)."""
     b, L, H, D = q.shape
-    CH = prefill_chunk(L, H // k.shape[2], window_left, start)
-    n_full = L // CH
-    if b == 1 and n_full >= 2:
-        return _prefill_attention_batched(q, k, v, k_cache, v_cache, window_left, start, CH)
+    total = start + L if total is None else int(total)
+    CH = prefill_chunk(total, H // k.shape[2], window_left)
+    head = min(L, (-start) % CH)                 # rows up to the next global chunk boundary
     outs = []
-    for s0 in range(0, L, CH):
+    if head:
+        lens = torch.full((b,), start, dtype=torch.int32, device=q.device)
+        outs.append(kvcache_attention(q[:, :head], k_cache, v_cache, k[:, :head], v[:, :head], cache_seqlens=lens,
+                                      causal=True, window_size=(window_left, -1), kv_len_hint=start))
+    if b == 1 and (L - head) // CH >= 2:
+        outs.append(_prefill_attention_batched(q[:, head:], k[:, head:], v[:, head:], k_cache, v_cache, window_left, start + head, CH))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    for s0 in range(head, L, CH):
         s1 = min(L, s0 + CH)
         lens = torch.full((b,), start + s0, dtype=torch.int32, device=q.device)
         outs.append(kvcache_attention(q[:, s0:s1], k_cache, v_cache, k[:, s0:s1], v[:, s0:s1], cache_seqlens=lens,
@@ -488,11 +497,12 @@ def prefill_attention(q, k, v, k_cache, v_cache, window_left: int = -1, start: i
     return torch.cat(outs, dim=1)
 
 
-def prefill_chunk(L: int, g: int, window_left: int, start: int) -> int:
-    """Prompt rows per chunk.  Long prompts of GQA models (g = H / Hkv >= 4) use g * chunk = 257..320 rows, which puts the
-    prefix part of every chunk on the warp-specialised kernel (ws_eligible: append chunks with kv_len_hint >= 4096); short
-    prompts, windows and small groups keep 64 (the chunking the reference-generated goldens were checked against)."""
-    if window_left < 0 and g >= 4 and start + L >= 8192 and 320 // g >= 32:
+def prefill_chunk(total: int, g: int, window_left: int) -> int:
+    """Prompt rows per chunk, a function of the WHOLE prompt (``total`` rows) only.  Long prompts of GQA models (g = H / Hkv
+    >= 4) use g * chunk = 257..320 rows, which puts the prefix part of every chunk on the streaming MFMA kernel (ws_eligible:
+    append chunks with kv_len_hint >= 4096); short prompts, windows and small groups keep 64 (the chunking the
+    reference-generated goldens were checked against)."""
+    if window_left < 0 and g >= 4 and total >= 8192 and 320 // g >= 32:
         return 320 // g
     return PREFILL_CHUNK
 

@@ -171,7 +171,7 @@ def tree_collapse(all_spec, all_llm_pred, tree_mask, cache_lens, non_leaf_len, m
     return pad_ids, acc_num, dbl, pad_map
 
 
-def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1, start=0):
+def prefill_attention(q, k, v, k_cache, v_cache, window_left=-1, start=0, total=None):
     L = q.shape[1]
     k_cache[:, start:start + L] = k
     v_cache[:, start:start + L] = v

@@ -453,6 +453,30 @@ def test_prefill_attention_vs_oracle(ops, H, Hkv, L, window, start):
     assert torch.equal(kc[:, :T].cpu(), k) and torch.equal(vc[:, :T].cpu(), v)
 
 
+def test_sharded_long_prompt_prefill_matches_the_single_gpu_calls(ops):
+    """a rank of a sequence-sharded prefill holds rows [start, start + L) of a LONG prompt (>= 8192 rows: 80-row
+    chunks for GQA-4).  With the chunk size taken from the whole prompt and chunk boundaries at global multiples of it, every
+    chunk the shard boundary does not cut is the very call the single-GPU prefill makes: bit-identical rows; the one chunk
+    the boundary cuts (here rows [4160, 4240) cut at 4200) differs by the block split only."""
+    H, Hkv, T, start = 8, 2, 8192 + 160, 4200
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    q = g(torch.randn(1, T, H, 128, generator=gen).to(torch.float16))
+    k = g(torch.randn(1, T, Hkv, 128, generator=gen).to(torch.float16))
+    v = g(torch.randn(1, T, Hkv, 128, generator=gen).to(torch.float16))
+    kc = torch.zeros(1, T + 64, Hkv, 128, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    whole = ops.prefill_attention(q, k, v, kc, vc)
+    CH = ops.prefill_chunk(T, H // Hkv, -1)
+    assert CH == 80
+    kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+    kc2[:, :start], vc2[:, :start] = k[:, :start], v[:, :start]
+    part = ops.prefill_attention(q[:, start:], k[:, start:], v[:, start:], kc2, vc2, start=start, total=T)
+    cut_end = (start + CH - 1) // CH * CH
+    assert torch.equal(part[:, cut_end - start:], whole[:, cut_end:]), "chunks behind the cut one: the same calls, the same bits"
+    assert_close_f16(part[:, :cut_end - start], whole[:, start:cut_end].cpu(), atol=2.1e-3, what="the chunk the shard boundary cuts")
+    assert torch.equal(kc2[:, :T], kc[:, :T]) and torch.equal(vc2[:, :T], vc[:, :T])
+
+
 @pytest.mark.parametrize("n_splits", [0, 2, 11])
 def test_append_attention_large_batch_is_batch_independent(ops, n_splits):
     """Thousands of workgroups in flight: 64 identical batch elements of an append call (64 new rows behind a 704-key
