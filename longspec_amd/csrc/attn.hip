@@ -828,9 +828,9 @@ __device__ __forceinline__ void qk_block_pf(f32x4 (&s)[2][QT], const typename E:
             for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[k4][kt], qf[qt][k4], s[kt][qt]);
 }
 
-template <typename E, bool S_ROLE>
+template <typename E, int QT, bool S_ROLE>           // QT row tiles per pair: 5 (17..20 tiles per row block), 3 (two row chunks of 12 tiles)
 __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int split, int pair) {
-    constexpr int QT = WS_QT;
+    static_assert(QT <= WS_QT, "the P buffers and the reference slots are laid out for WS_QT tiles per pair");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -925,7 +925,16 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow[qt] * p.q_ss +
                                       (long)head * p.q_sh + g4 * 8;
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) qf[qt][k4] = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+            for (int k4 = 0; k4 < 4; ++k4) {
+                qf[qt][k4] = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+                // Padding rows (rows m >= M of the last tile: 24 of the 320 a Llama-3 verify pass multiplies) carry ZERO queries
+                // and, below, an infinite reference -- their scores and numerators are exact zeros.  The kernel runs at the clock
+                // the power budget allows (the same launch takes 167 us on all-zero operands and 232 us on random ones,
+                // profiles/r3_power_bound.json), and an MFMA on zeros costs next to nothing.
+                if (m >= p.M)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[qt][k4][e] = E::from_f32(0.f);
+            }
         }
         float mref[QT];
         auto mask_tail = [&](f32x4 (&s)[2][QT], int b) {    // keys >= L of a block that crosses the end of the cache
@@ -965,6 +974,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 mask_tail(s_cur, 0);
                 if (mode == 0) row_max(s_cur, mref);
             }
+            if (mode != 1) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    if (row0 + qt * 16 + l15 >= p.M) mref[qt] = INFINITY;      // padding rows: p = 2^(0 - inf) = 0
+            }
             __builtin_amdgcn_s_barrier();          // K(0) is consumed: step 0 may overwrite its slot
             typedef __attribute__((address_space(3))) typename E::V8 lds_v8;
             // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS.  The row sums are NOT formed here: the
@@ -981,6 +995,13 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             pf[kt * 4 + e] = E::from_f32(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][qt][e], c, -mc)));
+#ifdef LS_MUTATE_SKIP_BLOCK
+                    // MUTANT (tests/test_gpu_ops.py::test_mutant_is_caught, never the product build): one 32-key block of one
+                    // split of one kv head contributes nothing
+                    if (j == 5 && split == 3 && kvh == 1)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[e] = E::from_f32(0.f);
+#endif
                     *(lds_v8*)(uintptr_t)(p_base + (j & 1) * WS_PBUF_B + qt * 1024) = pf;
                 }
             };
@@ -1009,7 +1030,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all 8 K-fragment LDS reads first,
                     __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);            // VALU work while they are in flight
 #pragma unroll
-                    for (int i = 0; i < 40; ++i) {
+                    for (int i = 0; i < 8 * QT; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // 1 MFMA
                         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);         // 6 VALU
                     }
@@ -1176,7 +1197,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
     }
 }
 
-template <typename E>
+template <typename E, int QT>
 __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const AttnK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.has_new && blockIdx.x == 0) {            // the new-key block keeps the 3,3,3,3,2,2,2,2 row split
@@ -1197,8 +1218,8 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const Attn
         // the S wave's VALU work).  Drawing the roles from the SIMD id actually read (HW_ID) costs three barriers and
         // measured 1.8 us SLOWER per launch at 16k, 6 us at 128k.
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < 4) prefix_path_ws<E, true>(p, smem, (int)blockIdx.x - p.has_new, w);
-        else prefix_path_ws<E, false>(p, smem, (int)blockIdx.x - p.has_new, w - 4);
+        if (w < 4) prefix_path_ws<E, QT, true>(p, smem, (int)blockIdx.x - p.has_new, w);
+        else prefix_path_ws<E, QT, false>(p, smem, (int)blockIdx.x - p.has_new, w - 4);
     }
     drain_lds_dma();
 }
@@ -1841,6 +1862,7 @@ struct Cfg {
     int qtA, qtB, rbA, RB, KS, tile, bpw, nstages, nd, pp, row_chunks, rows_per_chunk, threads, lds;
     int ws;        // 1: warp-specialised prefix path (attn_partial_ws_kernel), 2: ping-pong (attn_partial_pp_kernel)
     int pp_extra;
+    int ws_qt;     // row tiles per S/O pair of the warp-specialised kernel
 };
 
 // Workgroup shape for M = g*sq rows sharing one K/V stream (see the header comment).
@@ -1878,22 +1900,29 @@ Cfg pick_cfg(int M, bool ws_ok) {
     Cfg c;
     c.ws = 0;
     c.pp_extra = 0;
+    c.ws_qt = WS_QT;
     int tiles = (M + 15) / 16;
     c.row_chunks = 1;
     if (tiles > 24) {                   // g*sq > 384 rows: several row chunks re-read the K/V stream
         c.row_chunks = (M + 319) / 320;
         tiles = 20;
     }
+    const bool ws2 = ws_ok && kernel_choice() == 1 && tiles > 20 && tiles <= 24;
+    // 21..24 row tiles (GQA-5 x 74 verification rows = 370: QwQ) run as TWO row chunks of 12 tiles on the warp-specialised
+    // kernel with 3 tiles per S/O pair: six tiles per pair do not fit the S wave's registers (96 for Q^T alone), and the general
+    // kernel that served this shape until round 3 ran it at 0.23 of the HBM roofline.  The chunks re-read the K/V stream (from
+    // L2: the two workgroups of a split run side by side); half as many splits, the same partial volume.
     if (tiles <= 1) { c.qtA = c.qtB = 1; c.RB = 1; c.KS = 2; }
     else if (tiles <= 8) { c.qtA = c.qtB = 2; c.RB = (tiles + 1) / 2; c.KS = 2; }
     else if (tiles <= 16) { c.qtA = c.qtB = 2; c.RB = (tiles + 1) / 2; c.KS = 1; }
     else if (tiles <= 20) { c.qtA = 3; c.qtB = 2; c.RB = 8; c.KS = 1; }      // 3,3,3,3,2,2,2,2
     else { c.qtA = c.qtB = 3; c.RB = 8; c.KS = 1; }
+    if (ws2) { c.row_chunks = 2; c.qtA = c.qtB = 3; c.RB = 4; c.KS = 1; }      // new-key block: 4 workers x 3 tiles per chunk
     c.rbA = c.qtA == c.qtB ? c.RB : 4;
     c.bpw = c.KS == 1 ? 2 : 1;          // 32-key blocks per wave and tile
     c.tile = 64;
     c.nstages = 4;                      // 128 KB LDS ring; 2 tiles (64 KB) in flight beside the 2 being read
-    const int nw = c.RB * c.KS;
+    const int nw = ws2 ? 8 : c.RB * c.KS;
     c.nd = nw >= 8 ? 8 : (nw >= 4 ? 4 : (nw >= 2 ? 2 : 1));
     c.pp = (c.tile / 2) / c.nd;         // pieces (1 KB) per DMA wave and tile
     c.rows_per_chunk = (c.rbA * c.qtA + (c.RB - c.rbA) * c.qtB) * 16;
@@ -1907,7 +1936,12 @@ Cfg pick_cfg(int M, bool ws_ok) {
         c.pp_extra = tiles - 16;
     } else
 #endif
-    if (ws_ok && tiles > 16 && tiles <= 20) {       // row split of the new-key block stays 3,3,3,3,2,2,2,2
+    if (ws2) {
+        c.ws = 1;
+        c.ws_qt = 3;
+        c.nstages = WS_NEW_CAP / c.tile;
+        c.lds = WS_LDS;
+    } else if (ws_ok && tiles > 16 && tiles <= 20) {       // row split of the new-key block stays 3,3,3,3,2,2,2,2
         c.ws = 1;
         c.nstages = WS_NEW_CAP / c.tile;            // the new-block workgroup's capacity in the smaller ring
         c.lds = WS_LDS;
@@ -1998,9 +2032,9 @@ int launch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
     return LS_OK;
 }
 
-template <typename E>
+template <typename E, int QT>
 int launch_partial_ws(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
-    auto fn = attn_partial_ws_kernel<E>;
+    auto fn = attn_partial_ws_kernel<E, QT>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
@@ -2027,7 +2061,7 @@ int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
 #ifdef LS_WITH_PP
     if (c.ws == 2) return launch_partial_pp<E>(c, k, grid, s);
 #endif
-    if (c.ws) return launch_partial_ws<E>(c, k, grid, s);
+    if (c.ws) return c.ws_qt == 3 ? launch_partial_ws<E, 3>(c, k, grid, s) : launch_partial_ws<E, WS_QT>(c, k, grid, s);
     if (c.qtA == 1) return launch_partial<E, 1, 1>(c, k, grid, s);
     if (c.qtA == 2) return launch_partial<E, 2, 2>(c, k, grid, s);
     if (c.qtB == 2) return launch_partial<E, 3, 2>(c, k, grid, s);

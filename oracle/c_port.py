@@ -16,23 +16,23 @@ def load():
         if not os.path.exists(LIB):
             subprocess.check_call(["make", "-s", "-C", HERE])
         _lib = C.CDLL(LIB)
-        _lib.oracle_verify_attention_f16.restype = C.c_int
-        _lib.oracle_verify_attention_f16.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                                       C.c_int, C.c_float, C.c_void_p]
+        for fn in (_lib.oracle_verify_attention_f16, _lib.oracle_verify_attention_bf16):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     return _lib
 
 
 def verify_attention(q, k_new, v_new, k_cache, v_cache, L: int, tree_mask, last_layer: bool, scale=1.0 / (128 ** 0.5)):
-    """q [1,R,H,128] fp16 etc. (CPU, contiguous), caches [1,S,Hkv,128] modified in place. Returns [1,R,H,128] fp16."""
+    """q [1,R,H,128] fp16 or bf16 etc. (CPU, contiguous), caches [1,S,Hkv,128] modified in place. Returns [1,R,H,128] in q's dtype."""
     lib = load()
     _, R, H, D = q.shape
     Hkv = k_new.shape[2]
     out = torch.empty_like(q)
     tm = tree_mask.to(torch.int64).contiguous()
     for t in (q, k_new, v_new, k_cache, v_cache):
-        assert t.is_contiguous() and t.dtype == torch.float16 and not t.is_cuda
-    rc = lib.oracle_verify_attention_f16(q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(), k_cache.data_ptr(),
-                                         v_cache.data_ptr(), int(L), tm.data_ptr(), R, H, Hkv, int(last_layer), float(scale),
-                                         out.data_ptr())
+        assert t.is_contiguous() and t.dtype == q.dtype and q.dtype in (torch.float16, torch.bfloat16) and not t.is_cuda
+    fn = lib.oracle_verify_attention_f16 if q.dtype == torch.float16 else lib.oracle_verify_attention_bf16
+    rc = fn(q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(), k_cache.data_ptr(),
+            v_cache.data_ptr(), int(L), tm.data_ptr(), R, H, Hkv, int(last_layer), float(scale), out.data_ptr())
     assert rc == 0
     return out

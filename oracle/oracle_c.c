@@ -43,12 +43,25 @@ static inline uint16_t f2h(float f) {
     if (rem > 0x1000 || (rem == 0x1000 && (r & 1))) ++r;
     return (uint16_t)(s | r);
 }
-static inline float rh(float f) { return h2f(f2h(f)); }   /* one rounding to fp16 */
+/* bfloat16 <-> fp32 (round-to-nearest-even, NaN kept quiet): what `tensor.to(torch.bfloat16)` does */
+static inline float b2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline uint16_t f2b(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+/* storage dtype of the call: 0 = fp16, 1 = bf16 (file-scope so that the loops below read like the fp16 original; set once per
+ * call before the parallel region, read-only inside it) */
+static int g_bf16 = 0;
+static inline float ld(uint16_t h) { return g_bf16 ? b2f(h) : h2f(h); }
+static inline uint16_t st(float f) { return g_bf16 ? f2b(f) : f2h(f); }
+static inline float rh(float f) { return ld(st(f)); }   /* one rounding to the storage dtype */
 
 /* q [R,H,D], k_new/v_new [R,Hkv,D], caches [S,Hkv,D] (row stride Hkv*D), tree_mask [R,R] int64 */
-int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const uint16_t* v_new, uint16_t* k_cache,
-                                uint16_t* v_cache, int L, const int64_t* tree_mask, int R, int H, int Hkv, int last_layer,
-                                float scale, uint16_t* out) {
+static int verify_attention(const uint16_t* q, const uint16_t* k_new, const uint16_t* v_new, uint16_t* k_cache,
+                            uint16_t* v_cache, int L, const int64_t* tree_mask, int R, int H, int Hkv, int last_layer,
+                            float scale, uint16_t* out) {
     const int g = H / Hkv;
     const size_t rs = (size_t)Hkv * D;
     /* scatter (llama.py:396-399) */
@@ -69,12 +82,12 @@ int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const 
         float* lsum = (float*)malloc(sizeof(float) * R);
         if (!qf || !s || !kf || !acc || !pre_o || !pre_lse || !lsum) { fail = 1; goto done; }
         for (int r = 0; r < R; ++r)
-            for (int d = 0; d < D; ++d) qf[r * D + d] = h2f(q[((size_t)r * H + h) * D + d]);
+            for (int d = 0; d < D; ++d) qf[r * D + d] = ld(q[((size_t)r * H + h) * D + d]);
         /* ---- prefix: fp32 scores, fp32 statistics, P -> fp16 before P.V, one division (ref_ops._attend) */
         for (int j0 = 0; j0 < L; j0 += 64) {
             const int nj = L - j0 < 64 ? L - j0 : 64;
             for (int j = 0; j < nj; ++j)
-                for (int d = 0; d < D; ++d) kf[j * D + d] = h2f(k_cache[(size_t)(j0 + j) * rs + hk * D + d]);
+                for (int d = 0; d < D; ++d) kf[j * D + d] = ld(k_cache[(size_t)(j0 + j) * rs + hk * D + d]);
             for (int r = 0; r < R; ++r)
                 for (int j = 0; j < nj; ++j) {
                     float a = 0.f;
@@ -93,7 +106,7 @@ int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const 
         for (int j0 = 0; j0 < L; j0 += 64) {
             const int nj = L - j0 < 64 ? L - j0 : 64;
             for (int j = 0; j < nj; ++j)
-                for (int d = 0; d < D; ++d) kf[j * D + d] = h2f(v_cache[(size_t)(j0 + j) * rs + hk * D + d]);
+                for (int d = 0; d < D; ++d) kf[j * D + d] = ld(v_cache[(size_t)(j0 + j) * rs + hk * D + d]);
             for (int r = 0; r < R; ++r)
                 for (int j = 0; j < nj; ++j) {
                     const float p = s[(size_t)r * L + j0 + j];
@@ -112,7 +125,7 @@ int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const 
                 float a = 0.f;
                 for (int d = 0; d < D; ++d) {
                     const float qv = last_layer ? rh(qf[r * D + d] * scale) : qf[r * D + d];
-                    a += qv * h2f(k_new[((size_t)j * Hkv + hk) * D + d]);
+                    a += qv * ld(k_new[((size_t)j * Hkv + hk) * D + d]);
                 }
                 a = rh(a);
                 if (!last_layer) a = rh(a * scale);
@@ -126,17 +139,35 @@ int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const 
             for (int d = 0; d < D; ++d) cur[d] = 0.f;
             for (int j = 0; j < R; ++j) {
                 const float p = rh(sc[j] / l);
-                for (int d = 0; d < D; ++d) cur[d] += p * h2f(v_new[((size_t)j * Hkv + hk) * D + d]);
+                for (int d = 0; d < D; ++d) cur[d] += p * ld(v_new[((size_t)j * Hkv + hk) * D + d]);
             }
             const float w = rh(1.0f / (1.0f + expf(-(pre_lse[r] - cur_lse))));
             const float omw = rh(1.0f - w);
             for (int d = 0; d < D; ++d) {
                 const float a = rh(pre_o[r * D + d] * w), b = rh(rh(cur[d]) * omw);
-                out[((size_t)r * H + h) * D + d] = f2h(a + b);
+                out[((size_t)r * H + h) * D + d] = st(a + b);
             }
         }
     done:
         free(qf); free(s); free(kf); free(acc); free(pre_o); free(pre_lse); free(lsum);
     }
     return fail ? -1 : 0;
+}
+
+int oracle_verify_attention_f16(const uint16_t* q, const uint16_t* k_new, const uint16_t* v_new, uint16_t* k_cache,
+                                uint16_t* v_cache, int L, const int64_t* tree_mask, int R, int H, int Hkv, int last_layer,
+                                float scale, uint16_t* out) {
+    g_bf16 = 0;
+    return verify_attention(q, k_new, v_new, k_cache, v_cache, L, tree_mask, R, H, Hkv, last_layer, scale, out);
+}
+
+/* the same restatement on bfloat16 storage (how inference_qwq.py runs QwQ-32B: every rounding point of the reference rounds to
+ * the activation dtype, llama.py:387,406-420 with dtype = bfloat16) */
+int oracle_verify_attention_bf16(const uint16_t* q, const uint16_t* k_new, const uint16_t* v_new, uint16_t* k_cache,
+                                 uint16_t* v_cache, int L, const int64_t* tree_mask, int R, int H, int Hkv, int last_layer,
+                                 float scale, uint16_t* out) {
+    g_bf16 = 1;
+    const int rc = verify_attention(q, k_new, v_new, k_cache, v_cache, L, tree_mask, R, H, Hkv, last_layer, scale, out);
+    g_bf16 = 0;
+    return rc;
 }

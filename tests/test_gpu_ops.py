@@ -1,6 +1,8 @@
 """Parity of the HIP kernels (called through the C ABI) against the reference's golden
 vectors and the CPU oracle.  ``-m gpu``: needs a real MI355X."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -37,6 +39,27 @@ def assert_close_f16(got, want, atol=1.1e-3, frac=None, mean=1.5e-4, what=""):
     assert d.mean().item() <= mean, f"{what}: mean |diff| {d.mean().item():.3e} > {mean}"
     if frac is not None:
         assert (d > 0).float().mean().item() <= frac, f"{what}: {(d > 0).float().mean().item():.3%} elements differ"
+
+
+def assert_close_rel(got, want, ulps=2.0, noise=5.0, bits=11, what=""):
+    """Parity bar of SURVEY 8(d) at sizes where the outputs are SMALL (a soft-max over L ~ N(0,1) values has rms sqrt(e/L):
+    4.6e-3 at 128k, where an absolute 1e-3 bound is a fifth of the signal).  Two terms, both in units in the last place
+    (2^-bits relative; bits = 11 for fp16, 8 for bf16):
+      * `ulps` at the element's OWN magnitude -- the 16-bit roundings of the output and of the merge (llama.py:387);
+      * `noise` at the tensor's rms -- the algorithm's own rounding noise: the weights P are rounded to 16 bits before P.V
+        (the reference's flash-attn does the same), each by up to half an ulp RELATIVE TO A REFERENCE MAXIMUM THAT DEPENDS ON
+        THE KEY SPLIT, so two correct evaluations differ by a Gaussian of sigma ~ 0.8 ulp(rms): 5 ulp(rms) is its 6-sigma
+        tail over the 3e5 elements of a call.
+    |diff| <= 2^-bits * (ulps * |ref| + noise * rms(ref)), and the MEAN |diff| below one ulp(rms)."""
+    got, want = got.float().cpu(), want.float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    rms = want.pow(2).mean().sqrt().item()
+    tol = 2.0 ** -bits * (ulps * want.abs() + noise * rms)
+    d = (got - want).abs()
+    worst = (d / tol).max().item()
+    assert worst <= 1.0, f"{what}: max |diff| / (ulp bound) = {worst:.2f} (rms {rms:.3e}, max |diff| {d.max().item():.3e})"
+    assert d.mean().item() <= 2.0 ** -bits * rms, f"{what}: mean |diff| {d.mean().item():.3e} vs rms {rms:.3e}"
+    return worst, d.mean().item() / (2.0 ** -bits * rms)
 
 
 # --------------------------------------------------------------------------- #
@@ -416,7 +439,9 @@ def test_full_size_properties_qwq_bf16_32k(ops):
     o_full, lse_full = ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L)
     o_s, lse_s = ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L, n_splits=7)
     assert (o_full.float() - o_s.float()).abs().max().item() <= 2e-3
-    assert (lse_full - lse_s).abs().max().item() <= 5e-5
+    # bf16 numerators summed on the matrix pipe (warp-specialised kernel since round 3 for this 24-tile shape): the row sum is
+    # that of the ROUNDED weights -- 2^-9 relative per weight, averaged over the ~1000-4000 keys of a split
+    assert (lse_full - lse_s).abs().max().item() <= 2e-4
     g_ = H // Hkv
     for h0 in range(0, H, 10):
         qh = q[0, :, h0:h0 + 10].float().permute(1, 0, 2)
@@ -513,28 +538,54 @@ def test_append_attention_large_batch_is_batch_independent(ops, n_splits):
 # --------------------------------------------------------------------------- #
 # BASELINE sizes: the whole hybrid call against the oracle, then size-independent properties
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("L,last_layer", [(16384, False), (131072, False), (131072 - 21, True)])
-def test_full_size_verify_attention_vs_oracle(ops, L, last_layer):
-    """The metric's own sizes (Llama-3-8B heads, 74 rows, 16k and 128k prefixes, one ragged length): prefix
-    flash-decoding + KV scatter + tree-masked part + fp16 merge of the HIP path against the OpenMP C restatement of the
-    reference (oracle/oracle_c.c, ~1 s of host time per call at 128k) -- not a property: element by element."""
+FULL_SIZE = [  # (H, Hkv, L, last_layer, dtype): BASELINE.json's head layouts at their own prefix lengths
+    (32, 8, 16384, False, torch.float16),         # configs[1]: Llama-3-8B, 16k
+    (32, 8, 131072, False, torch.float16),        # configs[2]: Llama-3-8B, 128k (the metric's size)
+    (32, 8, 131072 - 21, True, torch.float16),    #   ragged length, last layer (pre-scaled q)
+    (40, 40, 8192, False, torch.float16),         # configs[3]: LongChat-13B (MHA), GovReport-length prefix
+    (40, 8, 32768, False, torch.bfloat16),        # configs[4]: QwQ-32B, bf16, 32k prefix
+]
+
+
+@pytest.mark.parametrize("H,Hkv,L,last_layer,dtype", FULL_SIZE, ids=lambda v: str(v).replace("torch.", ""))
+def test_full_size_verify_attention_vs_oracle(ops, H, Hkv, L, last_layer, dtype):
+    """Every BASELINE config's own size and head layout (74 rows): prefix flash-decoding + KV scatter + tree-masked part +
+    16-bit merge of the HIP path against the OpenMP C restatement of the reference (oracle/oracle_c.c, fp16 and bf16; ~1 s of
+    host time per call at 128k) -- not a property: element by element, and with a RELATIVE bound: two units in the last place at
+    the element's own magnitude (+ the same at the tensor's rms), because at these lengths the outputs are small (rms 4.6e-3 at
+    128k) and an absolute 1e-3 would not notice an error two orders of magnitude above an ulp.  tools/build_variant.py builds
+    a library that drops ONE 32-key block of ONE split (-DLS_MUTATE_SKIP_BLOCK): test_mutant_is_caught checks that this test
+    fails on it."""
     from oracle import c_port
-    H, Hkv = 32, 8
     q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 4000 + L % 97, a=4)
     gen = torch.Generator(device="cpu").manual_seed(L)
-    kc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
-    vc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
-    kc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(torch.float16)
-    vc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(torch.float16)
+    kc = torch.zeros(1, L + 128, Hkv, 128, dtype=dtype)
+    vc = torch.zeros(1, L + 128, Hkv, 128, dtype=dtype)
+    kc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(dtype)
+    vc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).to(dtype)
+    q, k, v = (t.to(dtype) for t in (q, k, v))
     kc_r, vc_r = kc.clone(), vc.clone()
     ref = c_port.verify_attention(q, k, v, kc_r, vc_r, L, tm, last_layer)
     kc_g, vc_g = g(kc), g(vc)
     cl = torch.tensor([L], dtype=torch.int32)
     out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), last_layer, kv_len_hint=L)
-    assert_close_f16(out, ref, atol=2.1e-3, what=f"L={L}")
+    assert out.dtype == dtype
+    assert_close_rel(out, ref, ulps=2.0, bits=11 if dtype == torch.float16 else 8, what=f"H={H}/{Hkv} L={L}")
     assert torch.equal(kc_g[:, L:L + 74].cpu(), kc_r[:, L:L + 74]) and torch.equal(vc_g[:, L:L + 74].cpu(), vc_r[:, L:L + 74])
     assert torch.equal(kc_g[:, :L].cpu(), kc[:, :L])
 
+
+def test_mutant_is_caught():
+    """The metric-size parity test must have teeth: a library built with -DLS_MUTATE_SKIP_BLOCK (the warp-specialised kernel
+    zeroes the weights of ONE 32-key block -- block 5 of split 3 of kv head 1 -- out of 4096) has to FAIL it.  The mutant is
+    built by __graft_entry__.build() / tools/build_variant.py; it is never the library the product loads."""
+    import subprocess
+    mutant = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "longspec_amd", "_lib", "liblongspec_hip_mutant.so")
+    assert os.path.exists(mutant), "build it: python tools/build_variant.py mutant -DLS_MUTATE_SKIP_BLOCK"
+    env = dict(os.environ, LONGSPEC_HIP_LIB=mutant)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_full_size_verify_attention_vs_oracle and 131072-False"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "max |diff| / (ulp bound)" in r.stdout, r.stdout[-1500:]
 
 
 @pytest.mark.parametrize("L", [16384, 131072])
@@ -552,7 +603,7 @@ def test_full_size_properties(ops, L):
     o_full, lse_full = ops.kvcache_attention(qg, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L)
     # (2)
     o_s, lse_s = ops.kvcache_attention(qg, kc, vc, cache_seqlens=cl, return_softmax_lse=True, kv_len_hint=L, n_splits=5)
-    assert (o_full.float() - o_s.float()).abs().max().item() <= 5e-4
+    assert_close_rel(o_s, o_full, ulps=2.0, what=f"split-count invariance L={L}")
     assert (lse_full - lse_s).abs().max().item() <= 2e-5
     # (1)
     h = L // 2 + 13
@@ -567,7 +618,7 @@ def test_full_size_properties(ops, L):
     n_o = R * H * 128
     out, _, lse = ops.lse_merge(torch.stack([r[:n_o].view(1, R, H, 128) for r in recs]),
                                 torch.stack([r[n_o:].view(1, H, R) for r in recs]), dtype=torch.float16)
-    assert (out.float() - o_full.float()).abs().max().item() <= 5e-4
+    assert_close_rel(out, o_full, ulps=2.0, what=f"LSE merge of two shards L={L}")
     assert (lse - lse_full).abs().max().item() <= 2e-5
     # (3) dense fp32 reference on the GPU, 4 heads at a time
     g_ = H // Hkv
@@ -577,5 +628,5 @@ def test_full_size_properties(ops, L):
         vh = vc[0, :L, h0 // g_:(h0 + 8) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
         s = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(128)
         ref = torch.matmul(torch.softmax(s, -1), vh).permute(1, 0, 2)
-        assert (o_full[0, :, h0:h0 + 8].float() - ref).abs().max().item() <= 1e-3
+        assert_close_rel(o_full[0, :, h0:h0 + 8], ref, ulps=2.0, what=f"dense fp32 soft-max L={L} heads {h0}..")
         assert (lse_full[0, h0:h0 + 8] - torch.logsumexp(s, -1)).abs().max().item() <= 1e-4

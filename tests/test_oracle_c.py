@@ -25,3 +25,18 @@ def test_c_port_matches_python_oracle_gqa():
     out = c_port.verify_attention(q, k, v, kc, vc, 777, tm, False)
     d = (out.float() - ref.float()).abs()
     assert d.max().item() <= 1.1e-3 and (d > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("last_layer", [False, True])
+def test_c_port_bf16_matches_python_oracle(last_layer):
+    """The bfloat16 form of the C restatement (cfg5: QwQ-32B runs in bf16; tests/test_gpu_ops.py uses it at 32k) against the
+    Python oracle evaluated in bf16: the same rounding points, one bf16 ulp on a sliver of elements (fp32 summation order)."""
+    q, k, v, kc, vc, tm = toy.verify_inputs(10, 2, 333, 5, a=3)
+    q, k, v, kc, vc = (t.to(torch.bfloat16) for t in (q, k, v, kc, vc))
+    cl = torch.tensor([333], dtype=torch.int32)
+    ref = ref_ops.target_verify_attention(q, k, v, kc.clone(), vc.clone(), cl, tm, last_layer)
+    out = c_port.verify_attention(q, k, v, kc, vc, 333, tm, last_layer)
+    assert out.dtype == torch.bfloat16
+    d = (out.float() - ref.float()).abs()
+    assert d.max().item() <= 2.0 ** -8 * ref.float().abs().max().item() and (d > 0).float().mean().item() < 0.02
+    assert torch.equal(kc[:, 333:333 + 74], k) and torch.equal(vc[:, 333:333 + 74], v)

@@ -27,6 +27,12 @@ def main():
     ap.add_argument("--splits", type=int, default=0)
     ap.add_argument("--mode", default="verify", choices=["verify", "prefix"])
     ap.add_argument("--sq", type=int, default=74)
+    ap.add_argument("--zeros", action="store_true", help="all-zero K/V/q: the same instruction stream with no operand toggling (how much of the time is the clock the power budget allows)")
+    ap.add_argument("--gap-us", type=float, default=0.0, help="idle time between calls (a cooler chip clocks higher)")
+    ap.add_argument("--round-like", type=int, default=0, metavar="MB",
+                    help="between two attention calls stream MB megabytes through a copy kernel, the way a decode round puts ~190 us "
+                         "of weight-streaming GEMMs between them (436 MB per layer for Llama-3-8B): the attention kernel then runs at "
+                         "the clock it gets inside a round, not at the one a back-to-back loop of itself is throttled to")
     args = ap.parse_args()
     dev = "cuda"
     for L in args.L:
@@ -38,6 +44,9 @@ def main():
         kc = torch.randn(1, L + 512, Hkv, 128, generator=gen).to(torch.float16).to(dev)
         vc = torch.randn(1, L + 512, Hkv, 128, generator=gen).to(torch.float16).to(dev)
         q, k, v = q.to(dev), k.to(dev), v.to(dev)
+        if args.zeros:
+            for t in (q, k, v, kc, vc):
+                t.zero_()
         bits = ops.pack_tree_mask(tm.to(dev))
         cl = torch.tensor([L], dtype=torch.int32, device=dev)
 
@@ -50,15 +59,41 @@ def main():
             call()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(args.iters):
-            call()
-        e.record()
-        torch.cuda.synchronize()
-        us = s.elapsed_time(e) * 1e3 / args.iters
+        if args.round_like > 0:
+            src = torch.empty(args.round_like * (1 << 20) // 2, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
+            for _ in range(3):
+                call()
+                dst.copy_(src)
+            for a_, b_ in evs:
+                a_.record()
+                call()
+                b_.record()
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            us = sum(a_.elapsed_time(b_) for a_, b_ in evs) * 1e3 / args.iters
+        elif args.gap_us > 0:
+            import time
+            tot = 0.0
+            for _ in range(args.iters):
+                s.record()
+                call()
+                e.record()
+                torch.cuda.synchronize()
+                tot += s.elapsed_time(e) * 1e3
+                time.sleep(args.gap_us * 1e-6)
+            us = tot / args.iters
+        else:
+            s.record()
+            for _ in range(args.iters):
+                call()
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 1e3 / args.iters
         by = algo_bytes(L, H, Hkv, R=args.sq)
         flops = 4 * args.sq * H * 128 * L
-        print(json.dumps({"mode": args.mode, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
+        print(json.dumps({"mode": args.mode, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
                           "algo_GBps": round(by / us / 1e3, 1), "frac_of_8TBps": round(by / us / 1e3 / 8000, 4),
                           "TFLOPs": round(flops / us / 1e6, 1)}))
 
