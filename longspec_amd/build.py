@@ -40,6 +40,26 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _write_usage(remarks: str, path: str) -> None:
+    """Per-kernel register / scratch figures from the compiler's -Rpass-analysis=kernel-resource-usage remarks, kept next to the
+    object (``_lib/<src>.usage.json``).  tests/test_build_resources.py reads them: a streaming kernel that starts spilling (one
+    innocent-looking edit of the split arithmetic cost attn_partial_ws_kernel 512 registers of scratch and a factor 3.4 in
+    round 3) is a build failure, not something to find with a profiler."""
+    import json
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -47,11 +67,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        if force or _stale(obj, [sp] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+        usage = obj.replace(".o", ".usage.json")
+        if force or _stale(obj, [sp] + HEADERS) or not os.path.exists(usage):
+            cmd = [hipcc] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", sp, "-o", obj]
             if verbose:
                 print("[longspec_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            _write_usage(r.stderr, usage)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr)
+                raise subprocess.CalledProcessError(r.returncode, cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
