@@ -86,21 +86,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
-def build_variant(name: str, defines, force: bool = False, verbose: bool = True) -> str:
-    """``_lib/liblongspec_hip_<name>.so``: the same library with extra ``-D`` flags on attn.hip -- diagnostic and TEST builds
+def build_variant(name: str, defines, force: bool = False, verbose: bool = True, sources=("attn.hip",)) -> str:
+    """``_lib/liblongspec_hip_<name>.so``: the same library with extra ``-D`` flags on `sources` -- diagnostic and TEST builds
     only (loaded through LONGSPEC_HIP_LIB, never by default).  ``mutant`` (-DLS_MUTATE_SKIP_BLOCK) is the library
     tests/test_gpu_ops.py::test_mutant_is_caught expects the metric-size parity test to reject."""
     build(verbose=verbose)
     hipcc = _hipcc()
     out = os.path.join(LIBDIR, f"liblongspec_hip_{name}.so")
-    src = os.path.join(CSRC, "attn.hip")
-    obj = os.path.join(LIBDIR, f"attn_{name}.o")
-    if force or _stale(obj, [src] + HEADERS):
-        cmd = [hipcc] + FLAGS + list(defines) + ["-c", src, "-o", obj]
-        if verbose:
-            print("[longspec_amd.build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    objs = [obj if s_ == "attn.hip" else os.path.join(LIBDIR, s_.replace(".hip", ".o")) for s_ in SOURCES]
+    objs = []
+    for s_ in SOURCES:
+        if s_ not in sources:
+            objs.append(os.path.join(LIBDIR, s_.replace(".hip", ".o")))
+            continue
+        src = os.path.join(CSRC, s_)
+        obj = os.path.join(LIBDIR, s_.replace(".hip", f"_{name}.o"))
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [hipcc] + FLAGS + list(defines) + ["-c", src, "-o", obj]
+            if verbose:
+                print("[longspec_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
     if force or _stale(out, objs):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out
