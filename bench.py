@@ -318,6 +318,8 @@ def main():
                     help="diagnostic: every rank uses cuda:0.  (Full-size kernels of two processes cannot co-reside on one GPU: a rank "
                          "spinning for its peer's record keeps the peer's attention kernel off the CUs until the wait times out -- "
                          "the cross-check then moves the run to the collective.)")
+    ap.add_argument("--no-vocab-parallel", action="store_true",
+                    help="N > 1 (or --shard-path): keep the lm_head replicated instead of sharding it by vocabulary over the ranks")
     ap.add_argument("--shard-path", action="store_true",
                     help="diagnostic: take the sequence-sharded attention path (partial -> reduce -> all-gather -> finish) even "
                          "with one rank, to price its extra launches without a second GPU")
@@ -395,7 +397,7 @@ def main():
     synth_kv(m, Ls, L_total, max_rows, device, seed=4321 + rank)
     if world > 1 or args.shard_path:
         from longspec_amd.dist import KVShard
-        shard = KVShard(rank, world, shard_rows=Ls)
+        shard = KVShard(rank, world, shard_rows=Ls, vocab_parallel=not args.no_vocab_parallel)
         for layer in m.model.layers:
             layer.self_attn.shard = shard
         m.glide.cross_attn.shard = shard
@@ -528,7 +530,9 @@ def main():
                                + ("" if weak or args.model != "llama3-8b-262k" or L_total != 131072 else
                                   " [BASELINE.json metric config: Llama-3-8B @128k ctx]"),
                    "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
-                   "parallelism": "1 GPU" if world == 1 else f"prefix KV sequence-sharded x{world}, weights replicated"},
+                   "parallelism": "1 GPU" if world == 1 else
+                   f"prefix KV sequence-sharded x{world}, lm_head " + ("replicated" if args.no_vocab_parallel else f"vocabulary-sharded x{world}")
+                   + ", layer weights replicated"},
         "tau": round(tau, 3), "rounds_per_s": round(args.steps / elapsed, 3),
         "hip_graphs": bool(graphs and st.graphs is not False),
     }

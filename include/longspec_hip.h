@@ -225,6 +225,22 @@ int ls_logprob_topk(const void* logits, int rows, int vocab, int64_t ld, int dty
 int ls_argmax_rows(const void* logits, int rows, int vocab, int64_t ld, int dtype, int64_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same two operators with the lm_head SHARDED BY VOCABULARY over the ranks of a node (no counterpart in the reference, which
+ * replicates: llama_glide.py:474).  A "record" is what stage 1 produces per (8192-logit chunk, row): the chunk's max, its sum of
+ * exp(x - max) and its k largest logits with their GLOBAL columns -- rows * (2 + 2k) floats per chunk slot, chunk-major.
+ *   ls_topk_stage1   this rank's slice logits_local [rows, vocab_local] (global columns col_base .. , col_base a multiple of
+ *                    ls_topk_chunk()) -> records [nslots][rows][2 + 2k]; slots beyond the slice are written as empty records, so
+ *                    that every rank can contribute the same number of slots to an all-gather;
+ *   ls_topk_stage2   all ranks' slots in rank order = global chunk order -> the log-soft-max top-k (argmax = 0: out_vals [k],
+ *                    out_idx [k] = row * vocab + column, history [rows] or NULL) or the per-row arg-max (argmax = 1: k = 1,
+ *                    out_idx [rows], out_vals [rows] or NULL).
+ * Bit-identical to ls_logprob_topk / ls_argmax_rows on the gathered logits for any number of ranks. */
+int ls_topk_chunk(void);
+int ls_topk_stage1(const void* logits_local, int rows, int vocab_local, int64_t ld, int dtype, int k, int col_base, int nslots,
+                   float* records, void* stream);
+int ls_topk_stage2(const float* records, int rows, int vocab, int k, int nslots, const float* history, int argmax, float* out_vals,
+                   int64_t* out_idx, void* stream);
+
 /* ---- beam-tree bookkeeping of a round (K10) ----------------------------------------------
  * The reference spells these steps as a few dozen tiny tensor ops per round
  * (longspec/test/llama_glide.py:1019-1121); each is one launch here, one workgroup per batch row. */

@@ -74,6 +74,9 @@ SYMBOLS = {
     "ls_topk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ls_logprob_topk": (C.c_int, [_P, _I, _I, _L, _I, _P, _I, _P, _P, _P, C.c_size_t, _P]),
     "ls_argmax_rows": (C.c_int, [_P, _I, _I, _L, _I, _P, _P, C.c_size_t, _P]),
+    "ls_topk_chunk": (C.c_int, []),
+    "ls_topk_stage1": (C.c_int, [_P, _I, _I, _L, _I, _I, _I, _I, _P, _P]),
+    "ls_topk_stage2": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "ls_lse_merge": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ls_pack_tree_mask": (C.c_int, [_P, _I, _I, _I, _P, _I, _P]),
     "ls_rmsnorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, C.c_float, _I, _P]),

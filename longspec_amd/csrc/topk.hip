@@ -13,6 +13,13 @@
 //            fixed chunk order, then the candidates' values ((x - m) - lse) + history[row] -- the
 //            reference's operation order in fp32 -- and the global top-k, sorted descending.
 //
+// Vocabulary-parallel form (round 3, the lm_head sharded over the ranks of a node): the records are laid out CHUNK-major,
+// [chunk slot][row][2 + 2k], so that the slots a rank owns are one contiguous block.  ls_topk_stage1 fills a rank's slots
+// from its slice of the logits (columns reported as GLOBAL columns; slots beyond its slice get an empty record: max -inf, sum 0,
+// no candidate), the blocks are all-gathered, ls_topk_stage2 merges all slots in slot order.  Slot order IS global chunk order
+// and an empty record adds exactly +0.0f to the row sum, so values and indices are bit-identical to the one-GPU call for any
+// number of ranks (stage 1 of a chunk never depended on the other chunks).
+//
 // Ties (equal fp32 values; fp16 logits collide often) go to the smaller flat index row * V + column, which
 // is also what `argmax` returns in PyTorch.  Latency-bound (256 KB .. 18 MB of L2-resident logits):
 // reported in microseconds, not against a roofline.
@@ -26,9 +33,9 @@ constexpr int TK_MAXK = 64;          // also bounded by TK_THREADS (sentinel pad
 
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
-// ws layout per (row, chunk): float max, float sum, then k x (float value, int column), in no particular order
-__device__ __forceinline__ float* ws_rec(float* ws, int row, int chunk, int nchunks, int k) {
-    return ws + ((long)row * nchunks + chunk) * (2 + 2 * k);
+// record of (chunk slot, row): float max, float sum, then k x (float value, int column), in no particular order; chunk-major
+__device__ __forceinline__ float* ws_rec(float* ws, int row, int slot, int rows, int k) {
+    return ws + ((long)slot * rows + row) * (2 + 2 * k);
 }
 
 // 16-bit float pattern -> unsigned key that orders like the value (no NaNs on this path)
@@ -118,7 +125,8 @@ __device__ __forceinline__ void find_bin(const int* hist, int want, bool from_to
 // cross-lane arg-max (measured 2.5 us per round).
 template <typename E>
 __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E::T* __restrict__ logits, long ldl, int V, int k,
-                                                                int nchunks, float* __restrict__ ws) {
+                                                                int col_base, float* __restrict__ ws) {
+    // V = columns of THIS slice (local), col_base = global column of its column 0; grid.x = slots to fill, grid.y = rows
     __shared__ float s_red[8];
     __shared__ int s_hist[256];
     __shared__ int s_sel[4];          // [0] bin / threshold, [1] count beyond, [2] output cursor, [3] scratch
@@ -127,6 +135,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E
     const typename E::T* src = logits + (long)row * ldl;
     const int base = chunk * TK_CHUNK;
     const int n_valid = min(TK_CHUNK, V - base);
+    if (n_valid <= 0) {               // a slot beyond this rank's slice of the vocabulary: the empty record
+        float* rec = ws_rec(ws, row, chunk, gridDim.y, k);
+        if (tid == 0) { rec[0] = -INFINITY; rec[1] = 0.f; }
+        if (tid < k) { rec[2 + 2 * tid] = -INFINITY; reinterpret_cast<int*>(rec)[3 + 2 * tid] = 0x7fffffff; }
+        return;
+    }
     const int kk = min(k, n_valid);
 
     uint32_t raw[16];                 // 32 logits as 16-bit patterns; element e = j*8 + i sits at column col0[j] + i
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E
         col_limit = s_sel[0];
     }
     // ---- emit exactly kk candidates (any order), pad with sentinels up to k
-    float* rec = ws_rec(ws, row, chunk, nchunks, k);
+    float* rec = ws_rec(ws, row, chunk, gridDim.y, k);
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
         const unsigned key = order_key(bits(e));
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E
         if (valid(e) && (key > T || (key == T && c <= col_limit))) {
             const int slot = atomicAdd(&s_sel[2], 1);
             rec[2 + 2 * slot] = val(e);
-            reinterpret_cast<int*>(rec)[3 + 2 * slot] = c;
+            reinterpret_cast<int*>(rec)[3 + 2 * slot] = col_base + c;
         }
     }
     if (tid < k - kk) {
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
             float bv = -INFINITY;
             int bi = 0x7fffffff;
             for (int c = 0; c < nchunks; ++c) {
-                const float* rec = ws + ((long)row * nchunks + c) * rec_f;
+                const float* rec = ws + ((long)c * R + row) * rec_f;
                 const float v = rec[2];
                 const int i = reinterpret_cast<const int*>(rec)[3];
                 if (better(v, i, bv, bi)) { bv = v; bi = i; }
@@ -279,8 +293,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
     // ---- per row: max and log-sum-exp in fixed chunk order.  All global loads of this kernel are issued in
     // independent batches (a dependent chain of L2 round trips per candidate cost 35 us in the first version).
     __shared__ float s_cm[128 * 4], s_cs[128 * 4], s_h[128];     // R * nchunks <= 512 (host-checked)
-    for (int i = tid; i < R * nchunks; i += TK_THREADS) {
-        const float2 ms = *reinterpret_cast<const float2*>(ws + (long)i * rec_f);
+    for (int i = tid; i < R * nchunks; i += TK_THREADS) {         // i = row * nchunks + slot; records are slot-major
+        const float2 ms = *reinterpret_cast<const float2*>(ws + ((long)(i % nchunks) * R + i / nchunks) * rec_f);
         s_cm[i] = ms.x;
         s_cs[i] = ms.y;
     }
@@ -307,8 +321,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < MAXOWN; ++j) {
         const int id = min(j * TK_THREADS + tid, ncand - 1);           // clamped: every load is unconditional
-        const int rc = id / k, slot = id - rc * k;                     // rc = row * nchunks + chunk
-        crow[j] = rc / nchunks;
+        const int rc = id / k, slot = id - rc * k;                     // rc = chunk slot * R + row (the records' own order)
+        crow[j] = rc % R;
         ld[j] = *reinterpret_cast<const float2*>(ws + (long)rc * rec_f + 2 + 2 * slot);
     }
 #pragma unroll
@@ -363,37 +377,81 @@ size_t ls_topk_workspace_bytes(int rows, int vocab, int k) {
     return (size_t)rows * nchunks * (2 + 2 * k) * sizeof(float);
 }
 
-static int topk_impl(const void* logits, int rows, int vocab, int64_t ld, int dtype, const float* history, int k, int mode,
-                     float* out_vals, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream, const char* what) {
-    if (!logits || !out_idx || !workspace) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null pointer", what);
+static int topk_check(const void* logits, int rows, int vocab, int64_t ld, int dtype, int k, const char* what) {
+    if (!logits) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null pointer", what);
     if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "%s: dtype", what);
     if (rows < 1 || vocab < 8 || vocab % 8 != 0 || ld < vocab || ld % 8 != 0)
         LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows=%d vocab=%d ld=%ld (vocab and ld must be multiples of 8)", what, rows, vocab, (long)ld);
     if (k < 1 || k > TK_MAXK) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: k=%d (1..%d)", what, k, TK_MAXK);
-    const int nchunks = (vocab + TK_CHUNK - 1) / TK_CHUNK;
+    return LS_OK;
+}
+
+static int stage1(const void* logits, int rows, int vocab_local, int64_t ld, int dtype, int k, int col_base, int nslots, float* records,
+                  hipStream_t s) {
+    if (dtype == LS_F16)
+        hipLaunchKernelGGL(topk_chunk_kernel<ElemF16>, dim3(nslots, rows), dim3(TK_THREADS), 0, s,
+                           static_cast<const _Float16*>(logits), (long)ld, vocab_local, k, col_base, records);
+    else
+        hipLaunchKernelGGL(topk_chunk_kernel<ElemBF16>, dim3(nslots, rows), dim3(TK_THREADS), 0, s,
+                           static_cast<const __bf16*>(logits), (long)ld, vocab_local, k, col_base, records);
+    LS_CHECK_LAUNCH("topk_chunk_kernel");
+    return LS_OK;
+}
+
+static int stage2(const float* records, int rows, int vocab, int k, int nslots, const float* history, int mode, float* out_vals,
+                  int64_t* out_idx, hipStream_t s, const char* what) {
+    if (!records || !out_idx) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null pointer", what);
     if (mode == 0) {
         if (rows > 128) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: more than 128 rows", what);
-        if ((long)rows * nchunks * k > 256L * 20) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows*chunks*k too large", what);
+        if ((long)rows * nslots * k > 256L * 20) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows*chunks*k too large", what);
         if ((long)rows * vocab < k) LS_FAIL(LS_ERR_INVALID_ARG, "%s: k exceeds the number of logits", what);
         if ((long)rows * vocab >= 0x7fffffffL) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows * vocab >= 2^31", what);
-        if ((long)rows * nchunks > 512) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows * chunks > 512", what);
+        if ((long)rows * nslots > 512) LS_FAIL(LS_ERR_UNSUPPORTED, "%s: rows * chunks > 512", what);
         if (!out_vals) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null out_vals", what);
     }
-    if (workspace_bytes < ls_topk_workspace_bytes(rows, vocab, k)) LS_FAIL(LS_ERR_WORKSPACE, "%s: workspace too small", what);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    float* ws = static_cast<float*>(workspace);
-    if (dtype == LS_F16)
-        hipLaunchKernelGGL(topk_chunk_kernel<ElemF16>, dim3(nchunks, rows), dim3(TK_THREADS), 0, s,
-                           static_cast<const _Float16*>(logits), (long)ld, vocab, k, nchunks, ws);
-    else
-        hipLaunchKernelGGL(topk_chunk_kernel<ElemBF16>, dim3(nchunks, rows), dim3(TK_THREADS), 0, s,
-                           static_cast<const __bf16*>(logits), (long)ld, vocab, k, nchunks, ws);
-    LS_CHECK_LAUNCH("topk_chunk_kernel");
     const int grid2 = mode == 1 ? (rows + TK_THREADS - 1) / TK_THREADS : 1;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(grid2), dim3(TK_THREADS), 0, s, ws, rows, vocab, k, nchunks, history, mode, out_vals,
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode, out_vals,
                        out_idx);
     LS_CHECK_LAUNCH("topk_merge_kernel");
     return LS_OK;
+}
+
+static int topk_impl(const void* logits, int rows, int vocab, int64_t ld, int dtype, const float* history, int k, int mode,
+                     float* out_vals, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream, const char* what) {
+    int rc = topk_check(logits, rows, vocab, ld, dtype, k, what);
+    if (rc) return rc;
+    if (!workspace) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null pointer", what);
+    const int nchunks = (vocab + TK_CHUNK - 1) / TK_CHUNK;
+    if (workspace_bytes < ls_topk_workspace_bytes(rows, vocab, k)) LS_FAIL(LS_ERR_WORKSPACE, "%s: workspace too small", what);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* ws = static_cast<float*>(workspace);
+    rc = stage1(logits, rows, vocab, ld, dtype, k, 0, nchunks, ws, s);
+    if (rc) return rc;
+    return stage2(ws, rows, vocab, k, nchunks, history, mode, out_vals, out_idx, s, what);
+}
+
+int ls_topk_chunk(void) { return TK_CHUNK; }
+
+int ls_topk_stage1(const void* logits_local, int rows, int vocab_local, int64_t ld, int dtype, int k, int col_base, int nslots,
+                   float* records, void* stream) {
+    if (vocab_local == 0) {           // a rank that owns no column (more ranks than chunks): nothing but empty records
+        if (!records || rows < 1 || k < 1 || k > TK_MAXK || nslots < 1 || (dtype != LS_F16 && dtype != LS_BF16))
+            LS_FAIL(LS_ERR_INVALID_ARG, "ls_topk_stage1: bad arguments for an empty slice");
+        return stage1(records, rows, 0, 8, dtype, k, col_base, nslots, records, static_cast<hipStream_t>(stream));
+    }
+    int rc = topk_check(logits_local, rows, vocab_local, ld, dtype, k, "ls_topk_stage1");
+    if (rc) return rc;
+    if (!records || nslots < 1 || col_base < 0 || col_base % TK_CHUNK != 0 || (long)nslots * TK_CHUNK < vocab_local)
+        LS_FAIL(LS_ERR_INVALID_ARG, "ls_topk_stage1: records null, col_base %d not a multiple of %d, or %d slots < the slice's chunks",
+                col_base, TK_CHUNK, nslots);
+    return stage1(logits_local, rows, vocab_local, ld, dtype, k, col_base, nslots, records, static_cast<hipStream_t>(stream));
+}
+
+int ls_topk_stage2(const float* records, int rows, int vocab, int k, int nslots, const float* history, int argmax, float* out_vals,
+                   int64_t* out_idx, void* stream) {
+    if (rows < 1 || vocab < 8 || k < 1 || k > TK_MAXK || nslots < 1) LS_FAIL(LS_ERR_INVALID_ARG, "ls_topk_stage2: bad dims");
+    return stage2(records, rows, vocab, k, nslots, history, argmax ? 1 : 0, out_vals, out_idx, static_cast<hipStream_t>(stream),
+                  "ls_topk_stage2");
 }
 
 int ls_logprob_topk(const void* logits, int rows, int vocab, int64_t ld, int dtype, const float* history, int k, float* out_vals,

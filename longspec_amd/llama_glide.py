@@ -744,14 +744,19 @@ class LlamaGlide(LlamaForCausalLM):
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                    llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
                                    llm_kv_len=st.target_cache_lens_for_draft, exec_type="decoding")
-        # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits
-        logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
-        vocab_size = logits.size(-1)
-        if st.temperature > 0:                         # spec_logits[:, 0] = current_logp (:1025, G8: log-probs, not logits)
-            if st.spec_logits is None:
-                st.spec_logits = torch.zeros((bsz, Fn, vocab_size), dtype=torch.float32, device=logits.device)
-            st.spec_logits[:, 0] = logits[:, 0].float().log_softmax(dim=-1)
-        topk_logp, pred_ids = ops.logprob_topk(logits, None, cand[0])
+        # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits.  Under a shard
+        # with `vocab_parallel` every rank multiplies by its slice of the lm_head only (dist.KVShard.head_select)
+        vsh = last_attn.shard if (last_attn.shard is not None and last_attn.shard.vocab_parallel and st.temperature == 0) else None
+        vocab_size = self.lm_head.out_features
+        if vsh is not None:
+            topk_logp, pred_ids = vsh.head_select(self.lm_head, hidden_states[:, a - 1, :], ops, k=cand[0])
+        else:
+            logits = self.lm_head(hidden_states[:, a - 1, :]).view(bsz, 1, -1)
+            if st.temperature > 0:                     # spec_logits[:, 0] = current_logp (:1025, G8: log-probs, not logits)
+                if st.spec_logits is None:
+                    st.spec_logits = torch.zeros((bsz, Fn, vocab_size), dtype=torch.float32, device=logits.device)
+                st.spec_logits[:, 0] = logits[:, 0].float().log_softmax(dim=-1)
+            topk_logp, pred_ids = ops.logprob_topk(logits, None, cand[0])
         # the root's children (:1021-1027): tree_mask rows + diagonal, all_spec, log-prob sums, and
         # `draft_cache_lens += a - 1` -- one launch, which also hands back the next pass's positions and packed mask
         position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp, pred_ids, vocab_size, 0, 1,
@@ -766,10 +771,14 @@ class LlamaGlide(LlamaForCausalLM):
                                        llm_kv_len=st.target_cache_lens_for_draft, exec_type="tree_decoding",
                                        tree_mask=tree_mask[:, lo:mid, :mid], tree_mask_bits=mask_bits)
             # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
-            level_logits = self.lm_head(hidden_states)
-            if st.temperature > 0:                     # spec_logits[:, lo:mid] = current_logp (:1074)
-                st.spec_logits[:, lo:mid] = level_logits.float().log_softmax(dim=-1)
-            topk_logp_sum, topk_indices = ops.logprob_topk(level_logits, history_logp_sum[:, lo:mid], cand[ms])
+            if vsh is not None:
+                topk_logp_sum, topk_indices = vsh.head_select(self.lm_head, hidden_states, ops, k=cand[ms],
+                                                              history=history_logp_sum[:, lo:mid])
+            else:
+                level_logits = self.lm_head(hidden_states)
+                if st.temperature > 0:                 # spec_logits[:, lo:mid] = current_logp (:1074)
+                    st.spec_logits[:, lo:mid] = level_logits.float().log_softmax(dim=-1)
+                topk_logp_sum, topk_indices = ops.logprob_topk(level_logits, history_logp_sum[:, lo:mid], cand[ms])
             # father = index // vocab, token = index % vocab, mask row = father's row + diagonal (:1056-1075)
             position_ids, mask_bits = ops.tree_grow(tree_mask, all_spec, history_logp_sum, topk_logp_sum, topk_indices,
                                                     vocab_size, lo, mid, base=st.draft_cache_lens, want_next=ms + 1 < gamma)
@@ -781,7 +790,10 @@ class LlamaGlide(LlamaForCausalLM):
         hidden_states = hidden_states[:, a - 1:a + Fn - 1]
         if st.temperature > 0:
             return self.lm_head(hidden_states)         # the stochastic branch continues in tree_round_stochastic
-        all_llm_pred = ops.argmax_rows(self.lm_head(hidden_states))
+        if vsh is not None:
+            all_llm_pred = vsh.head_select(self.lm_head, hidden_states, ops, argmax=True).view(bsz, -1)
+        else:
+            all_llm_pred = ops.argmax_rows(self.lm_head(hidden_states))
         # ---- A: accept / reject tree collapse + last-layer KV row move (:1104-1116); the accepted rows start at
         # cache_lens + a - 1 (:1104), the cache lengths themselves advance in the commit below
         sh = last_attn.shard

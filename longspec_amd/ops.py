@@ -200,6 +200,50 @@ def argmax_rows(logits: torch.Tensor) -> torch.Tensor:
     return out.view(shape)
 
 
+TOPK_CHUNK = 8192          # logits per stage-1 record (ls_topk_chunk(); checked at first use)
+
+
+def topk_stage1(logits_local: Optional[torch.Tensor], rows: int, k: int, col_base: int, nslots: int, out: torch.Tensor, dtype=None):
+    """Stage 1 of the vocabulary-parallel ``logprob_topk`` / ``argmax_rows``: this rank's slice of the lm_head output
+    ``logits_local`` [rows, V_local] (global columns ``col_base`` ...; None when the rank owns no column) -> ``nslots`` chunk
+    records [nslots, rows, 2 + 2k] fp32 written into ``out`` (flat, e.g. the exchange's send buffer).  Returns the record view."""
+    lib = _C.load()
+    assert lib.ls_topk_chunk() == TOPK_CHUNK
+    rec = 2 + 2 * k
+    n = nslots * rows * rec
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n
+    if logits_local is None:
+        v_local, ld, ptr = 0, 8, out.data_ptr()            # (never read: every slot is an empty record)
+        dt = _C.LS_F16 if dtype in (None, torch.float16) else _C.LS_BF16
+    else:
+        _dev(logits_local)
+        assert logits_local.dim() == 2 and logits_local.shape[0] == rows and logits_local.stride(1) == 1
+        v_local, ld, ptr, dt = logits_local.shape[1], logits_local.stride(0), logits_local.data_ptr(), _dtype(logits_local)
+    _C.check(lib.ls_topk_stage1(ptr, rows, v_local, ld, dt, k, col_base, nslots, out.data_ptr(), _stream()), "ls_topk_stage1")
+    return out[:n].view(nslots, rows, rec)
+
+
+def topk_stage2(records: torch.Tensor, rows: int, vocab: int, k: int, history: Optional[torch.Tensor], argmax: bool):
+    """Stage 2: all ranks' records [slots, rows, 2 + 2k] in rank order (= global chunk order) -> what ``logprob_topk``
+    (values [1, k], flat indices [1, k]) or ``argmax_rows`` (indices [rows]) return on the gathered logits, bit for bit."""
+    _dev(records, history)
+    assert records.dtype == torch.float32 and records.is_contiguous() and records.shape[1] == rows and records.shape[2] == 2 + 2 * k
+    lib = _C.load()
+    dev = records.device
+    if argmax:
+        idx = torch.empty((rows,), dtype=torch.int64, device=dev)
+        _C.check(lib.ls_topk_stage2(records.data_ptr(), rows, vocab, 1, records.shape[0], None, 1, None, idx.data_ptr(), _stream()),
+                 "ls_topk_stage2")
+        return idx
+    vals = torch.empty((1, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((1, k), dtype=torch.int64, device=dev)
+    if history is not None:
+        history = history.to(torch.float32).contiguous()
+    _C.check(lib.ls_topk_stage2(records.data_ptr(), rows, vocab, k, records.shape[0], history.data_ptr() if history is not None else None,
+                                0, vals.data_ptr(), idx.data_ptr(), _stream()), "ls_topk_stage2")
+    return vals, idx
+
+
 _linear_timing = None
 
 

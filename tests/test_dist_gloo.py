@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, run_name, q, sharded_prefill=False):
+def _worker(rank, world, port, run_name, q, sharded_prefill=False, vocab_chunk=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -31,6 +31,8 @@ def _worker(rank, world, port, run_name, q, sharded_prefill=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle_ops
     from longspec_amd.dist import KVShard, shard_model_kv
+    if vocab_chunk:          # the toy vocabulary (512) is one 8192-chunk: a smaller unit makes every rank own a real slice
+        KVShard.VOCAB_CHUNK = vocab_chunk
     from longspec_amd.llama_glide import LlamaGlide
     run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
     m = LlamaGlide(run["cfg"], ops=oracle_ops)
@@ -85,6 +87,39 @@ def test_sequence_sharded_tree_decode_matches_single_process(world, run_name):
     for rank, out, count, num in res:
         assert torch.equal(out, run["tree_out"]), f"rank {rank}: token ids differ from the single-process reference"
         assert (count, num) == (run["tree_count"], run["tree_num"])
+
+
+@pytest.mark.parametrize("world,run_name,vocab_chunk", [(2, "mixed", 128), (3, "gqa_mixed", 64), (3, "forced", 200)])
+def test_vocabulary_parallel_lm_head_matches_single_process(world, run_name, vocab_chunk):
+    """Round 3: under a shard every rank multiplies by ITS slice of the lm_head (whole chunks of the vocabulary, dealt in rank
+    order; 512 toy entries in chunks of 128 / 64 / 200 -> 2, 3 and 1 chunk per rank, the last rank of the third case owning
+    112 columns only) and the ranks select the beam candidates / the verified tokens jointly (dist.KVShard.head_select, here in
+    its generic form: the logits are gathered).  Token ids and counters equal the single-process golden run on every rank."""
+    run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, run_name, q, False, vocab_chunk)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for rank, out, count, num in res:
+        assert torch.equal(out, run["tree_out"]), f"rank {rank}: token ids differ from the single-process reference"
+        assert (count, num) == (run["tree_count"], run["tree_num"])
+
+
+def test_vocab_slices_tile_the_vocabulary():
+    from longspec_amd.dist import KVShard
+    for V in (512, 32000, 128256, 152064):
+        for W in (1, 2, 3, 4, 8):
+            cover, ncls = [], set()
+            for r in range(W):
+                ncl, lo, hi = KVShard(r, W, 16).vocab_slice(V)
+                ncls.add(ncl)
+                assert (lo % KVShard.VOCAB_CHUNK == 0 or lo == hi == V) and lo <= hi <= V and hi - lo <= ncl * KVShard.VOCAB_CHUNK
+                cover.append((lo, hi))
+            assert len(ncls) == 1 and cover[0][0] == 0 and cover[-1][1] == V
+            assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
 @pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree")])

@@ -62,3 +62,38 @@ def test_argmax_rows(R, V):
     want = logits.argmax(dim=-1)
     # equal maxima (fp16 collisions): PyTorch-CPU and this kernel both return the first one
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("R,V,k,W", [(1, 128256, 4, 8), (16, 128256, 16, 8), (16, 128256, 16, 3), (4, 152064, 16, 2), (16, 32000, 16, 8),
+                                     (74, 128256, 1, 8), (74, 152064, 1, 2), (16, 512, 16, 2)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vocabulary_parallel_stages_are_bit_identical(R, V, k, W, dtype):
+    """Round 3 (the lm_head sharded by vocabulary, dist.KVShard.head_select): stage 1 on each rank's slice of the logits, the
+    ranks' chunk records concatenated in rank order, stage 2 on all of them -- values AND indices bit-identical to the one-GPU
+    operators (log-soft-max top-k for k > 1 rows <= 16, arg-max for the 74-row verification pass), for 2, 3 and 8 ranks,
+    including ranks that own no column at all (32000 = 4 chunks on 8 ranks; 512 = one chunk on 2)."""
+    from longspec_amd import ops
+    from longspec_amd.dist import KVShard
+    g = torch.Generator().manual_seed(R + V + k + W)
+    logits = (torch.randn(R, V, generator=g) * 2.5).to(dtype)
+    logits[:, V // 3] = logits[:, 2 * V // 3]                     # exact ties across chunks (and ranks): index order decides
+    logits = logits.cuda()
+    argmax = k == 1
+    hist = None if (argmax or R == 1) else (-torch.rand(1, R, generator=g) * 3).cuda()
+    if argmax:
+        want = ops.argmax_rows(logits)
+    else:
+        want = ops.logprob_topk(logits.view(1, R, V), hist, k)
+    recs, ncl = [], None
+    for r in range(W):
+        ncl, lo, hi = KVShard(r, W, 16).vocab_slice(V)
+        buf = torch.full((ncl * R * (2 + 2 * k),), float("nan"), dtype=torch.float32, device="cuda")
+        local = logits[:, lo:hi].contiguous() if hi > lo else None
+        recs.append(ops.topk_stage1(local, R, k, lo, ncl, buf, dtype=dtype).clone())
+    allrec = torch.cat(recs, dim=0).contiguous()
+    assert allrec.shape == (W * ncl, R, 2 + 2 * k) and not torch.isnan(allrec[..., 0::2]).any()      # (odd fields past 1 are int columns)
+    got = ops.topk_stage2(allrec, R, V, k, hist.reshape(-1) if hist is not None else None, argmax)
+    if argmax:
+        assert torch.equal(got, want)
+    else:
+        assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
