@@ -326,6 +326,10 @@ def main():
     ap.add_argument("--config", type=int, default=None, choices=range(len(BASELINE_CONFIGS)),
                     help="one of BASELINE.json's configs by index: sets the model / prefix / dtype and names the config verbatim in "
                          "config.workload (configs[2] is the default workload; 0 runs the Vicuna-7B 4k case on the GPU)")
+    ap.add_argument("--method", default="tree", choices=["tree", "seq"],
+                    help="tree = tree_spec_generate rounds (the metric); seq = the chain method (spec_generate, gamma 4) on the same model "
+                         "and prefix -- configs[3]'s chain-vs-tree A/B (inference_long-bench.py --method seq | tree).  The line of a seq "
+                         "run carries no roofline objects (its target pass is a 5-row decode pass, not the 74-row verification)")
     args = ap.parse_args()
     if args.config is not None:
         preset = BASELINE_CONFIGS[args.config]
@@ -425,6 +429,36 @@ def main():
         s_ = m.begin_tree_decode(first, lens, L_total, TREE, max_gen, eos_id=-1)
         s_.eos = None                                    # run a fixed number of rounds
         return s_
+
+    if args.method == "seq":
+        # ---- the chain method (llama_glide.py:621-774), one GPU: K rounds of gamma = 4 draft steps + one 5-row target pass
+        assert world == 1 and not args.shard_path, "--method seq is a one-GPU A/B leg"
+        gamma = 4
+        with torch.inference_mode():
+            cst = m.begin_chain_decode(first, lens.clone(), lens.to(torch.int64), L_total, gamma=gamma,
+                                       max_gen_len=(gamma + 1) * (rounds + 2) + 8, eos_id=-1)
+            cst.eos = None                                   # a fixed number of rounds
+            for _ in range(args.warmup):
+                m.chain_round(cst)
+            barrier()
+            tok0 = cst.emitted
+            t0 = time.time()
+            for _ in range(args.steps):
+                m.chain_round(cst)
+            barrier()
+            elapsed = time.time() - t0
+            tokens = cst.emitted - tok0
+        out = {"metric": "accepted tokens/sec (chain speculative decode, gamma 4, temperature 0)", "value": round(tokens / elapsed, 3),
+               "unit": "accepted tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
+               "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
+               "config": {"workload": (BASELINE_CONFIGS[args.config]["name"] + " -- " if args.config is not None else "") +
+                                      f"{args.model} dims + longspec draft layer, {L_total}-token synthetic prefix, --method seq (chain, gamma {gamma}), "
+                                      "temperature 0, batch 1", "prefix_tokens": L_total, "kv_rows_per_gpu": Ls, "parallelism": "1 GPU",
+                          "method": "seq"},
+               "tau": round(tokens / args.steps, 3), "rounds_per_s": round(args.steps / elapsed, 3), "hip_graphs": False}
+        print(json.dumps(out), flush=True)
+        return
 
     exchange_note = exchange_forced
     if world > 1 and shard.peer is not None and not args.no_exchange_check:
@@ -529,7 +563,7 @@ def main():
                                f"({Ls} rows of KV per GPU), tree_shape 4 16 16 16 16, temperature 0, batch 1"
                                + ("" if weak or args.model != "llama3-8b-262k" or L_total != 131072 else
                                   " [BASELINE.json metric config: Llama-3-8B @128k ctx]"),
-                   "prefix_tokens": L_total, "kv_rows_per_gpu": Ls,
+                   "prefix_tokens": L_total, "kv_rows_per_gpu": Ls, "method": "tree",
                    "parallelism": "1 GPU" if world == 1 else
                    f"prefix KV sequence-sharded x{world}, lm_head " + ("replicated" if args.no_vocab_parallel else f"vocabulary-sharded x{world}")
                    + ", layer weights replicated"},

@@ -376,105 +376,128 @@ class LlamaGlide(LlamaForCausalLM):
         bsz = input_ids.size(0)
         assert bsz == 1, "the reference's hot path is batch 1 (SURVEY section 1)"
         dev = input_ids.device
-        output_ids = input_ids.new_zeros((bsz, max_gen_len + gamma))
-        spec_mask = input_ids.new_zeros((bsz, max_gen_len + gamma))
         self.set_max_gen_len(max_gen_len + 128)
         if not magic:
             self.glide.set_max_gen_len(max_gen_len + 128)
         P = int(input_ids.size(1))
         self._set_hints(P, P)
-        cache_lens = input_ids.new_zeros((bsz)).int()
         hidden_states = self.model.forward(input_ids, exec_type="magicdec_prefill" if magic else "prefill").last_hidden_state
         input_len = prompt_length
         rows = torch.arange(bsz, device=dev)
         logits = self.lm_head(hidden_states[rows, input_len - 1, :])
-        output_ids[:, 0] = logits.argmax(dim=-1)
-        cache_lens += input_len.int()
-        draft_cache_lens = cache_lens.clone()
-        spec_buffer = output_ids.new_zeros((bsz, gamma + 1))
-        spec_buffer[:, 0] = output_ids[:, 0]
-        # temperature > 0 (:639-640,704,709): the draft's fp32 logits of every step, for the rejection test of :716-736
-        spec_logits = logits.new_zeros((bsz, gamma + 1, logits.size(-1)), dtype=torch.float32) if temperature > 0 else None
-        if spec_logits is not None:
-            spec_logits[:, 0] = logits
+        cache_lens = input_ids.new_zeros((bsz)).int() + input_len.int()
         if not magic:                                    # glide prefill
             hidden_states = self.model.embed_tokens(input_ids)
             position_ids = torch.arange(0, input_ids.size(1), device=dev)[None, :]
             position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
             self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings, llm_kv=self._last_kv(),
-                       cache_lens=draft_cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
-        stream_rows = self.model.layers[0].self_attn.STREAM_SINK + self.model.layers[0].self_attn.STREAM_WINDOW
-        double_flag = False
-        input_len_i32 = input_len.to(device=dev, dtype=torch.int32).view(bsz).contiguous()
-        next_spec_start_token = output_ids.new_zeros((bsz, 2))
-        count = 0
-        num = 0
-        next_spec_start_token[:, 0] = output_ids[:, 0]
-        emitted = 1                      # host mirror of cache_lens - input_len + 1
-        eos = self._stop_id(eos_id, "spec")
+                       cache_lens=cache_lens.clone(), llm_kv_len=cache_lens.clone(), exec_type="prefill")
+        st = self.begin_chain_decode(logits.argmax(dim=-1), cache_lens, input_len, P, gamma, max_gen_len, eos_id, temperature,
+                                     drafter, first_logits=logits)
         _sync(input_ids)
         start_time = time.time()
         for out_index in range(1, max_gen_len):
-            bound = P + emitted + gamma + 2
-            self._set_hints(bound, bound)
-            for spec_steps in range(0, gamma):
-                if spec_steps == 0:
-                    if double_flag:
-                        draft_ids = next_spec_start_token[:, 0:2]
-                        position_ids = torch.arange(0, 2, device=dev)[None, :] + draft_cache_lens[:, None]
-                    else:
-                        draft_ids = next_spec_start_token[:, 0, None]
-                        position_ids = draft_cache_lens[:, None]
-                else:
-                    draft_ids = spec_buffer[:, spec_steps, None]
-                    position_ids = draft_cache_lens[:, None]
-                hidden_states = self.model.embed_tokens(draft_ids)
-                position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
-                if magic:        # the target drafts for itself over its streaming cache (:830-836)
-                    stream_lens = (draft_cache_lens - input_len.int() + stream_rows).to(torch.int32)
-                    self.model.set_kv_len_hint(stream_rows + emitted + gamma + 2)
-                    hidden_states = self.model.forward(draft_ids, position_embeddings=position_embeddings, cache_lens=stream_lens,
-                                                       exec_type="magicdec_decoding").last_hidden_state
-                    self.model.set_kv_len_hint(bound)
-                else:
-                    hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
-                                               llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
-                                               llm_kv_len=cache_lens, exec_type="decoding")
-                if double_flag and spec_steps == 0:
-                    draft_cache_lens += 2                    # 1 + double_input (batch 1: the host knows the flag)
-                    current_logp = self.lm_head(hidden_states[:, -2:, :])
-                    spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp)[:, 1]
-                    if spec_logits is not None:
-                        spec_logits[:, spec_steps + 1, :] = current_logp[:, 1, :]
-                else:
-                    draft_cache_lens += 1
-                    current_logp = self.lm_head(hidden_states[:, -1, :])
-                    spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp).view(-1,)
-                    if spec_logits is not None:
-                        spec_logits[:, spec_steps + 1, :] = current_logp
-            hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
-            llm_verify_logits = self.lm_head(hidden_states[:, -gamma - 1:, :])
-            llm_verify_output = self.ops.argmax_rows(llm_verify_logits)
-            accept = None
-            if temperature > 0:                              # :715-736
-                llm_verify_output, accept = self.ops.chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer,
-                                                                             llm_verify_output)
-            # acceptance by cumulative match, verified ids + bonus token -> output_ids, cache_lens += correct_len, the next
-            # round's start tokens and draft_cache_lens = cache_lens - double_input (:738-770): one launch, one host read
-            state = self.ops.chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, input_len_i32,
-                                          next_spec_start_token, eos, **({"accept_mask": accept} if accept is not None else {})).tolist()
-            n_ok, hit = state[0][0], any(row[1] for row in state)
-            double_flag = n_ok == gamma + 1
-            count += n_ok - 1
-            num += bsz
-            emitted += n_ok
-            if emitted - 1 + gamma + 2 > output_ids.size(1):
-                break
-            if hit:
+            if not self.chain_round(st):
                 break
         _sync(input_ids)
         elapsed_time = time.time() - start_time
-        return output_ids, count, num, elapsed_time, spec_mask
+        return st.output_ids, st.count, st.num, elapsed_time, st.spec_mask
+
+    def begin_chain_decode(self, first_token, cache_lens, input_len, prompt_bound: int, gamma=4, max_gen_len=64, eos_id=151645,
+                           temperature=0.0, drafter="glide", first_logits=None):
+        """State of the chain-speculation loop right after the prefills (``llama_glide.py:641-668``): ``first_token`` [bsz]
+        = the target's first generated token, ``cache_lens`` [bsz] int32 = valid rows of every cache (the draft's included),
+        ``input_len`` [bsz] = prompt length, ``prompt_bound`` = host-side bound of it.  Also the entry point of benchmarks
+        that time ``chain_round`` on synthetic KV (bench.py --method seq)."""
+        from types import SimpleNamespace
+        bsz = first_token.size(0)
+        dev = first_token.device
+        st = SimpleNamespace(gamma=gamma, magic=drafter == "magicdec", temperature=temperature, bsz=bsz, P=int(prompt_bound),
+                             max_gen_len=max_gen_len, count=0, num=0, emitted=1, double_flag=False)
+        st.output_ids = first_token.new_zeros((bsz, max_gen_len + gamma))
+        st.spec_mask = first_token.new_zeros((bsz, max_gen_len + gamma))
+        st.output_ids[:, 0] = first_token
+        st.cache_lens = cache_lens
+        st.draft_cache_lens = cache_lens.clone()
+        st.input_len = input_len
+        st.input_len_i32 = input_len.to(device=dev, dtype=torch.int32).view(bsz).contiguous()
+        st.spec_buffer = st.output_ids.new_zeros((bsz, gamma + 1))
+        st.spec_buffer[:, 0] = st.output_ids[:, 0]
+        # temperature > 0 (:639-640,704,709): the draft's fp32 logits of every step, for the rejection test of :716-736
+        st.spec_logits = None
+        if temperature > 0:
+            assert first_logits is not None
+            st.spec_logits = first_logits.new_zeros((bsz, gamma + 1, first_logits.size(-1)), dtype=torch.float32)
+            st.spec_logits[:, 0] = first_logits
+        st.next_spec_start_token = st.output_ids.new_zeros((bsz, 2))
+        st.next_spec_start_token[:, 0] = st.output_ids[:, 0]
+        st.eos = self._stop_id(eos_id, "spec")
+        st.stream_rows = self.model.layers[0].self_attn.STREAM_SINK + self.model.layers[0].self_attn.STREAM_WINDOW
+        return st
+
+    def chain_round(self, st) -> bool:
+        """One round of ``spec_generate`` / ``magicdec_generate`` (``llama_glide.py:670-770``): gamma draft steps, one
+        (gamma + 1)-row target pass, acceptance by cumulative match.  False = stop (EOS or the buffer is full)."""
+        gamma, magic, bsz, P = st.gamma, st.magic, st.bsz, st.P
+        dev = st.output_ids.device
+        output_ids, cache_lens, draft_cache_lens = st.output_ids, st.cache_lens, st.draft_cache_lens
+        spec_buffer, spec_logits, next_spec_start_token = st.spec_buffer, st.spec_logits, st.next_spec_start_token
+        bound = P + st.emitted + gamma + 2
+        self._set_hints(bound, bound)
+        for spec_steps in range(0, gamma):
+            if spec_steps == 0:
+                if st.double_flag:
+                    draft_ids = next_spec_start_token[:, 0:2]
+                    position_ids = torch.arange(0, 2, device=dev)[None, :] + draft_cache_lens[:, None]
+                else:
+                    draft_ids = next_spec_start_token[:, 0, None]
+                    position_ids = draft_cache_lens[:, None]
+            else:
+                draft_ids = spec_buffer[:, spec_steps, None]
+                position_ids = draft_cache_lens[:, None]
+            hidden_states = self.model.embed_tokens(draft_ids)
+            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            if magic:        # the target drafts for itself over its streaming cache (:830-836)
+                stream_lens = (draft_cache_lens - st.input_len.int() + st.stream_rows).to(torch.int32)
+                self.model.set_kv_len_hint(st.stream_rows + st.emitted + gamma + 2)
+                hidden_states = self.model.forward(draft_ids, position_embeddings=position_embeddings, cache_lens=stream_lens,
+                                                   exec_type="magicdec_decoding").last_hidden_state
+                self.model.set_kv_len_hint(bound)
+            else:
+                hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
+                                           llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
+                                           llm_kv_len=cache_lens, exec_type="decoding")
+            if st.double_flag and spec_steps == 0:
+                draft_cache_lens += 2                    # 1 + double_input (batch 1: the host knows the flag)
+                current_logp = self.lm_head(hidden_states[:, -2:, :])
+                spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp)[:, 1]
+                if spec_logits is not None:
+                    spec_logits[:, spec_steps + 1, :] = current_logp[:, 1, :]
+            else:
+                draft_cache_lens += 1
+                current_logp = self.lm_head(hidden_states[:, -1, :])
+                spec_buffer[:, spec_steps + 1] = self.ops.argmax_rows(current_logp).view(-1,)
+                if spec_logits is not None:
+                    spec_logits[:, spec_steps + 1, :] = current_logp
+        hidden_states = self.model.forward(spec_buffer, cache_lens=cache_lens, exec_type="decoding").last_hidden_state
+        llm_verify_logits = self.lm_head(hidden_states[:, -gamma - 1:, :])
+        llm_verify_output = self.ops.argmax_rows(llm_verify_logits)
+        accept = None
+        if st.temperature > 0:                               # :715-736
+            llm_verify_output, accept = self.ops.chain_accept_stochastic(spec_logits, llm_verify_logits, spec_buffer,
+                                                                         llm_verify_output)
+        # acceptance by cumulative match, verified ids + bonus token -> output_ids, cache_lens += correct_len, the next
+        # round's start tokens and draft_cache_lens = cache_lens - double_input (:738-770): one launch, one host read
+        state = self.ops.chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_cache_lens, st.input_len_i32,
+                                      next_spec_start_token, st.eos, **({"accept_mask": accept} if accept is not None else {})).tolist()
+        n_ok, hit = state[0][0], any(row[1] for row in state)
+        st.double_flag = n_ok == gamma + 1
+        st.count += n_ok - 1
+        st.num += bsz
+        st.emitted += n_ok
+        if st.emitted - 1 + gamma + 2 > output_ids.size(1):
+            return False
+        return not hit
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
