@@ -856,11 +856,15 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
     // dumped into the (unused, prefix-only call) new_o region by workgroup (split 1, kv head 0) -- tools/ws_prof.py
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long pt = 0;
+    unsigned long long marks[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // launch timeline of the wave (absolute 100 MHz ticks)
+#define WS_MARK(i) do { marks[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    WS_MARK(0);                                                  // entry (after the address set-up above)
 #define WS_T0() do { pt = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define WS_TS(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); prof[i] += n_ - pt; pt = n_; } while (0)
 #else
 #define WS_T0()
 #define WS_TS(i)
+#define WS_MARK(i)
 #endif
     // one K piece and one V piece per wave and block.  Inside the cache (all but the split's last blocks) the source address is
     // a wave-uniform base (SGPRs) plus ONE per-lane offset register per operand -- the source-side swizzle of a wave's piece
@@ -952,6 +956,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             for (int qt = 0; qt < QT; ++qt)
                 if (mode != 2) mref[qt] = -INFINITY;
             pass_head();
+            WS_MARK(1);                            // blocks 0 and 1 have landed (Q loads issued before them)
             f32x4 s_cur[2][QT];
             if (mode == 0 && nblocks > 1) {        // block 1's share of the reference (block 0's follows)
                 qk_block<E, QT>(s_cur, qf, tb, k_addr(1));
@@ -969,6 +974,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     if (row0 + qt * 16 + l15 >= p.M) mref[qt] = INFINITY;      // padding rows: p = 2^(0 - inf) = 0
             }
             __builtin_amdgcn_s_barrier();          // K(0) is consumed: step 0 may overwrite its slot
+            WS_MARK(2);                            // reference look done
             typedef __attribute__((address_space(3))) typename E::V8 lds_v8;
             // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS.  The row sums are NOT formed here: the
             // O wave gets them from the matrix pipe (a ninth V^T tile whose row 0 is all ones: l = sum of the fp16 P it
@@ -1073,6 +1079,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             }
         };
         run_pass(0);
+        WS_MARK(3);                                        // step loop done
         if (tid == 0) *redo_flag = 0;
         __syncthreads();
         __syncthreads();                                   // (the O waves raise the flag in between)
@@ -1082,6 +1089,10 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             run_pass(2);
         }
 #ifdef LS_WS_PROF
+        WS_MARK(4);
+        if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && wave == 0 && lane < 8)
+            reinterpret_cast<unsigned long long*>(p.new_o)[16 + lane] = marks[0] * (lane == 0) + marks[1] * (lane == 1) + marks[2] * (lane == 2) +
+                                                                        marks[3] * (lane == 3) + marks[4] * (lane == 4);
         if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && wave == 0 && lane < 6)
             reinterpret_cast<unsigned long long*>(p.new_o)[lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
                                                                    prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
@@ -1149,6 +1160,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             }
         };
         run_pass(0);
+        WS_MARK(3);
         __syncthreads();
         {   // an fp16 P that overflowed (or an inf - inf behind it) leaves a non-finite row sum: redo with the true row maxima
             bool bad = false;
@@ -1168,6 +1180,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                                                                        prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
 #endif
         __syncthreads();                           // the pair's m*scale is in LDS
+        WS_MARK(5);                                // ready to write the partial
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const float lt = __shfl(lacc[qt][0], l15);       // (lanes g4 == 0 hold it)
@@ -1183,6 +1196,13 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
             }
         }
+#ifdef LS_WS_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_MARK(6);                                // partial stores acknowledged
+        if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && wave == 4 && lane < 8)
+            reinterpret_cast<unsigned long long*>(p.new_o)[24 + lane] = marks[0] * (lane == 0) + marks[3] * (lane == 3) +
+                                                                        marks[5] * (lane == 5) + marks[6] * (lane == 6);
+#endif
     }
 }
 

@@ -20,11 +20,16 @@ ws = max(ops.workspace_tensors(), key=lambda t: t.numel())
 n_parts = 32
 rows = 74 * H
 off = ((n_parts * rows * 128 * 4 + 255) // 256 * 256) + ((n_parts * rows * 4 + 255) // 256 * 256)
-raw = ws.view(torch.uint8)[off:off + 16 * 8].cpu().view(torch.int64).tolist()
+raw = ws.view(torch.uint8)[off:off + 32 * 8].cpu().view(torch.int64).tolist()
 names = ["dma issue", "body (LDS reads, MFMA, soft-max / P.V)", "vmcnt wait (ladder + landing)", "lgkmcnt(0)", "barrier"]
 out = {}
 for role, base in (("S wave", 0), ("O wave", 8)):
     nb = raw[base + 5]
     out[role] = {"steps": nb, "ns_per_step": {n: round(raw[base + i] * 10.0 / max(nb, 1), 1) for i, n in enumerate(names)},
                  "total_ns_per_step": round(sum(raw[base:base + 5]) * 10.0 / max(nb, 1), 1)}
-print(json.dumps({"L": L, **out}))
+ms, mo = raw[16:24], raw[24:32]
+tl = {"S wave (us from its entry)": {"K/V blocks 0-1 landed": (ms[1] - ms[0]) / 100, "reference look done": (ms[2] - ms[0]) / 100,
+                                     "step loop done": (ms[3] - ms[0]) / 100, "after the redo check": (ms[4] - ms[0]) / 100},
+      "O wave (us from its entry)": {"step loop done": (mo[3] - mo[0]) / 100, "ready to write the partial": (mo[5] - mo[0]) / 100,
+                                     "partial stores acknowledged": (mo[6] - mo[0]) / 100}}
+print(json.dumps({"L": L, **out, "timeline": tl}))
