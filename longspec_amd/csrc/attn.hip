@@ -1233,6 +1233,387 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const Attn
     drain_lds_dma();
 }
 
+#ifdef LS_WITH_W4
+// ===================== four-wave prefix path: one wave per SIMD, 512 registers, one mixed instruction stream ==============
+// NOT DISPATCHED: the second measured negative of round 3, kept behind -DLS_WITH_W4 (tools/build_variant.py w4 -DLS_WITH_W4,
+// then LS_ATTN_KERNEL=f; tools/dbg_w4.py checks it against an fp32 reference).  With the compiler's MFMA builtins it is correct
+// and takes 301 us per 128k launch alone against 220 of the warp-specialised kernel (274 vs 199 as a verification call behind a
+// copy kernel); with the accumulators pinned to the AGPR half through asm MFMAs (-DLS_W4_ASM_MFMA: 0 scratch in the steady loop)
+// it is no faster and the results are wrong in a timing-dependent way.  tools/mb/w4_step.hip is the ceiling of the layout: the
+// same step written as ONE asm block with fixed registers runs 1.25-1.28 us on constant operands -- what the warp-specialised
+// kernel already does on zeros (1.26) -- because the lone wave of a SIMD eats every LDS wait itself.  profiles/r3_w4_vs_ws.json.
+// Round 3, second structural attempt.  tools/mb/issue_model.hip: behind one v_mfma_f32_16x16x32 two independent VALU / LDS
+// instructions issue for free (9.9 -> 10.9 ns per MFMA), the third costs 3.5 ns -- in the same wave or in the partner wave
+// alike.  The warp-specialised kernel gives its S wave 2.9 such fillers per MFMA and its O wave 0.5; the ping-pong kernel
+// separated the two kinds of work in time.  Here every SIMD runs ONE wave (the whole 512-entry register file) that owns 5 row
+// tiles end to end and whose step is one block of mutually independent work, software-pipelined two deep:
+//     QK^T of block j+1 (40 MFMAs, -> s_next)   P.V of block j-1 (40 MFMAs, <- pf_old)   soft-max of block j (s_cur -> pf_new)
+// = 80 MFMAs, ~105 VALU and 24 LDS fragment reads (1.6 fillers per MFMA) in the order  MFMA, MFMA, one score's soft-max.  P never
+// leaves registers, row sums are fp32 adds (lse as exact as the general kernel's), K and V are read from LDS by 4 waves instead of
+// 4 + 4 with no P round trip, and the only synchronisation is the ring hand-off: one 4-wave barrier per 32-key step.
+constexpr int W4_QT = 5;
+constexpr int W4_LA = 5;                          // blocks of DMA look-ahead
+constexpr int W4_NK = W4_LA + 1;                  // K(b) is read in step b-1
+constexpr int W4_NV = W4_LA + 3;                  // V(b) is read in step b+1
+constexpr int W4_RING_B = (W4_NK + W4_NV) * WS_BLK_B;
+constexpr int W4_LDS = W4_RING_B + 64 + 4 * W4_QT * 64 * 4;     // + the rows' soft-max references, parked for the epilogue
+constexpr int W4_NEW_CAP = W4_RING_B / (2 * ROWB);
+
+template <typename E>
+__device__ __forceinline__ void prefix_path_w4(const AttnK& p, char* smem, int split, int wave) {
+    constexpr int QT = W4_QT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int bi = blockIdx.z, kvh = blockIdx.y % p.Hkv, chunk = blockIdx.y / p.Hkv;
+    const int L = p.cache_seqlens[bi];
+    const float c = p.scale * LOG2E;
+    const int row0 = chunk * p.rows_per_chunk + wave * QT * 16;
+    // (nothing that is only needed in the prologue or the epilogue is kept in a register across the step loop: the vector half of
+    // the file holds two score sets, two weight sets and the fragments in flight, and a spilled lane constant costs more than
+    // its reload -- the compiler drains the DMA look-ahead with s_waitcnt vmcnt(0) in front of every scratch read)
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;
+    const LaneTbl tb = make_lane_tbl(l15, g4);
+    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
+    const long kc_row = p.kc_ss * 2;
+    int* redo_flag = reinterpret_cast<int*>(smem + W4_RING_B);
+    float* mref_lds = reinterpret_cast<float*>(smem + W4_RING_B + 64) + (wave * QT) * 64 + lane;      // [wave][qt][lane]
+
+    const int nb_all = (L + 31) / 32;
+    const int bps = (nb_all + p.n_splits - 1) / p.n_splits;
+    const int b_begin = split * bps;
+    const int n = max(0, min(b_begin + bps, nb_all) - b_begin);
+    const int last_key = L - 1;
+    const bool ragged = (b_begin + n) * 32 > L;
+
+    // two K pieces and two V pieces (4 keys each) per wave and block: pieces 2*wave, 2*wave + 1
+    const int kq_ = lane >> 4, pos_ = lane & 15;
+    unsigned koff_[2], voff_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = 2 * wave + i;
+        koff_[i] = (unsigned)(kq_ * kc_row) + ((pos_ ^ (((pc & 3) << 2) | kq_)) << 4);
+        voff_[i] = (unsigned)(kq_ * kc_row) + ((pos_ ^ ((((pc & 1) << 2) | kq_) << 1)) << 4);
+    }
+    auto k_addr = [&](int b) __attribute__((always_inline)) -> unsigned { return smem_a + (b % W4_NK) * WS_BLK_B; };
+    auto v_addr = [&](int b) __attribute__((always_inline)) -> unsigned { return smem_a + (W4_NK + b % W4_NV) * WS_BLK_B; };
+    auto dma = [&](int b) __attribute__((always_inline)) {
+        const int bg = b_begin + b;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = 2 * wave + i;
+            if (bg * 32 + 32 <= L) {
+                const long row = ((long)bg * 32 + pc * 4) * kc_row;
+                dma16_s(kc_base + row, koff_[i], k_addr(b) + pc * 1024);
+                dma16_s(vc_base + row, voff_[i], v_addr(b) + pc * 1024);
+            } else {
+                const int key = pc * 4 + kq_;
+                const long ka = min(bg * 32 + key, last_key);               // tail rows: re-read the last valid key (masked)
+                dma16(kc_base + ka * kc_row + ((pos_ ^ (key & 15)) << 4), smem + (b % W4_NK) * WS_BLK_B + pc * 1024);
+                dma16(vc_base + ka * kc_row + ((pos_ ^ ((key & 7) << 1)) << 4), smem + (W4_NK + b % W4_NV) * WS_BLK_B + pc * 1024);
+            }
+        }
+    };
+    auto wait_block = [&](int need, int issued) __attribute__((always_inline)) {              // blocks 0 .. issued-1 requested (4 pieces each)
+        if (need >= issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        wait_vmcnt(4 * (issued - 1 - need));
+    };
+
+    typename E::V8 qf[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int m = row0 + qt * 16 + l15;
+        const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
+        const int rrow = m < p.M ? m % p.sq : 0;
+        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow * p.q_ss +
+                                  (long)head * p.q_sh + g4 * 8;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            typename E::V8 v = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
+            if (m >= p.M)                                      // padding rows multiply zeros (see prefix_path_ws)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = E::from_f32(0.f);
+            // Q^T lives in the ACCUMULATOR half of the register file for the whole kernel (its only readers are the QK^T MFMAs'
+            // B operands): the value has to be BORN there -- a vector-half value with "a" uses is copied into a scratch quad of
+            // the accumulator half in front of every MFMA (and spilled in between)
+            asm volatile("" : "+a"(v));               // (an empty statement whose operand is pinned to the accumulator half)
+            qf[qt][k4] = v;
+        }
+    }
+
+    f32x4 acc[8][QT];
+    float lsum[QT], mref[QT], negmc[QT];
+    float pmax = 0.f;
+    f32x4 sA[2][QT], sB[2][QT];               // scores of two consecutive blocks
+    typename E::V8 pA[QT], pB[QT];            // weights of two consecutive blocks
+    typename E::V8 kf[4][2];
+    union VF {
+        struct { s16x4 a, b; } s;
+        typename E::V8 v;
+    } vf[8];
+
+    // fragment loaders: ONE k-step of K (two 16-key tiles) / ONE 16-column tile of V^T at a time -- the step body requests a
+    // fragment a few groups before its first MFMA and lets it die behind its last one (rolling: 24 registers of fragments live
+    // instead of 64; with all of them fetched up front the wave needs 14-28 registers more than the vector half has)
+    auto k_frag = [&](unsigned kbase, int k4) __attribute__((always_inline)) {
+        int kx = tb.kx;
+        asm volatile("" : "+v"(kx));           // see qk_block
+        const unsigned kb = kbase + tb.kb;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
+    };
+    auto v_frag = [&](unsigned vbase, int dt) __attribute__((always_inline)) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        int vx = tb.vx;
+        asm volatile("" : "+v"(vx));           // see qk_block
+        const unsigned va = vbase + tb.vb + ((dt ^ vx) << 5);
+        vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
+        vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
+    };
+    auto k_load = [&](unsigned kbase) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) k_frag(kbase, k4);
+    };
+    auto v_load = [&](unsigned vbase) __attribute__((always_inline)) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) v_frag(vbase, dt);
+    };
+    auto mask_tail = [&](f32x4 (&s)[2][QT], int b) __attribute__((always_inline)) {
+        const int ka0 = (b_begin + b) * 32;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ka0 + kt * 16 + g4 * 4 + e >= L) s[kt][qt][e] = -INFINITY;
+    };
+    auto row_max = [&](const f32x4 (&s)[2][QT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float v = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                                  fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+            mref[qt] = fmaxf(mref[qt], wave_xor_max_16_32(v));
+        }
+    };
+    // One step's work, as ONE unrolled sequence of 40 groups: { QK^T MFMA g, P.V MFMA g, the soft-max of score g }.
+    //   QK^T MFMA g:  k4 = g / 10, (qt, kt) = g % 10   -> an accumulator is revisited every 10th group
+    //   P.V  MFMA g:  dt = g / 5, qt = g % 5           -> every accumulator once
+    //   score g:      qt = g / 8, element g % 8
+    auto step_body = [&](auto has_qk_, auto has_pv_, unsigned kbase, unsigned vbase, f32x4 (&s_in)[2][QT], f32x4 (&s_out)[2][QT],
+                         typename E::V8 (&p_in)[QT], typename E::V8 (&p_out)[QT]) __attribute__((always_inline)) {
+        constexpr bool HAS_QK = decltype(has_qk_)::value, HAS_PV = decltype(has_pv_)::value;
+        if (HAS_QK) k_frag(kbase, 0);
+        if (HAS_PV) { v_frag(vbase, 0); v_frag(vbase, 1); }
+        if (HAS_QK) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s_out[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float ps[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) ps[qt] = 0.f;
+        float pe_prev = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8 * QT; ++g) {
+            if (HAS_QK && g % (2 * QT) == 0 && g / (2 * QT) + 1 < 4) k_frag(kbase, g / (2 * QT) + 1);     // one k-step ahead
+            if (HAS_PV && g % QT == 0 && g / QT + 2 < 8) v_frag(vbase, g / QT + 2);                       // two d tiles ahead
+            if (HAS_QK) {
+                const int k4 = g / (2 * QT), r = g % (2 * QT), qt = r >> 1, kt = r & 1;
+                E::mfma_b_a(kf[k4][kt], qf[qt][k4], s_out[kt][qt]);
+            }
+            if (HAS_PV) {
+                const int dt = g / QT, qt = g % QT;
+                E::mfma_acc_a(vf[dt].v, p_in[qt], acc[dt][qt]);
+            }
+            {
+                const int qt = g >> 3, e8 = g & 7, kt = e8 >> 2, e = e8 & 3;
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s_in[kt][qt][e], c, negmc[qt]));
+                ps[qt] += pe;
+                if (e8 & 1) {
+                    p_out[qt][e8 - 1] = E::from_f32(pe_prev);
+                    p_out[qt][e8] = E::from_f32(pe);
+                }
+                pe_prev = pe;
+            }
+#ifndef LS_W4_FREE_SCHED
+            __builtin_amdgcn_sched_barrier(0);     // pin the mix: nothing moves across a group boundary
+#endif
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            lsum[qt] += ps[qt];
+            pmax = fmaxf(pmax, ps[qt]);
+        }
+    };
+    // step j: [DMA j+1+LA] [fragments: K(j+1), V(j-1)] [QK^T(j+1) -> s_out | P.V(j-1) <- p_in | soft-max(s_in) -> p_out] [ring hand-off]
+    auto step = [&](int j, int& issued, auto has_qk_, auto has_pv_, f32x4 (&s_in)[2][QT], f32x4 (&s_out)[2][QT],
+                    typename E::V8 (&p_in)[QT], typename E::V8 (&p_out)[QT]) __attribute__((always_inline)) {
+        if (j + 1 + W4_LA < n) { dma(j + 1 + W4_LA); ++issued; }
+        step_body(has_qk_, has_pv_, k_addr(j + 1), v_addr(j - 1), s_in, s_out, p_in, p_out);
+        if (decltype(has_qk_)::value && ragged && j + 2 == n) {   // block j+1 is the split's last and crosses the end of the cache
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // (its MFMAs are asm statements: let them retire before compiler code reads s_out)
+            mask_tail(s_out, j + 1);
+        }
+        wait_block(j + 2, issued);                 // K(j+2) is multiplied in step j+1
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    auto qk_first = [&](unsigned kbase) __attribute__((always_inline)) {          // sA = S^T of one block, outside the pipeline (prologue, maxima pass)
+        k_load(kbase);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) sA[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) E::mfma_b_a(kf[k4][kt], qf[qt][k4], sA[kt][qt]);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the readers below are compiler code: let the last MFMAs retire)
+    };
+
+    auto max_pass = [&]() __attribute__((always_inline)) {                        // QK^T only, for the true row maxima (after a numerator near the fp16 range)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mref[qt] = -INFINITY;
+        int issued = 0;
+        for (; issued < min(n, 2); ++issued) dma(issued);
+        for (int b = 0; b < n; ++b) {
+            wait_block(b, issued);
+            __builtin_amdgcn_s_barrier();
+            qk_first(k_addr(b));
+            if (ragged && b == n - 1) mask_tail(sA, b);
+            row_max(sA);
+            __builtin_amdgcn_s_barrier();
+            if (issued < n) dma(issued++);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    auto main_pass = [&](bool have_ref) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            lsum[qt] = 0.f;
+            if (!have_ref) mref[qt] = -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                // pinned where it stands (an empty statement that "rewrites" the accumulator in the accumulator half): the
+                // compiler otherwise sinks the zeroing to just in front of the first asm MFMA that reads it (n = 1: measured
+                // wrong), closer than a write of the accumulator half may be to an MFMA that reads it
+                acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+a"(acc[dt][qt]));
+            }
+        }
+        asm volatile("s_nop 7" ::: "memory");
+        pmax = 0.f;
+        int issued = 0;
+        for (; issued < min(n, W4_LA + 1); ++issued) dma(issued);
+        wait_block(1, issued);                     // blocks 0 and 1
+        __builtin_amdgcn_s_barrier();
+        if (n == 0) return;
+        qk_first(k_addr(0));
+        if (ragged && n == 1) mask_tail(sA, 0);
+        if (!have_ref) row_max(sA);                // the reference: the row's maximum over the split's first 32 keys
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const bool pad = row0 + qt * 16 + l15 >= p.M;
+            if (pad) mref[qt] = INFINITY;          // padding rows: weights exactly zero
+            negmc[qt] = pad ? -INFINITY : -(mref[qt] == -INFINITY ? 0.f : mref[qt]) * c;
+            mref_lds[qt * 64] = mref[qt];          // (read back by the epilogue; not held across the loop)
+        }
+        // step 0 (no P.V yet), pairs of steps with the two score / weight register sets swapping roles, the last one or two
+        // QK^T steps, the last step (no QK^T), then the P.V of the last block.  Invariant at `tail`: scores of block j in sB,
+        // weights of block j-1 in pA.
+        auto pv_only = [&](typename E::V8 (&pw)[QT]) __attribute__((always_inline)) {
+            v_load(v_addr(n - 1));
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) E::mfma_acc_a(vf[dt].v, pw[qt], acc[dt][qt]);
+        };
+        if (n == 1) {
+            step(0, issued, F_{}, F_{}, sA, sB, pB, pA);
+            pv_only(pA);
+            return;
+        }
+        step(0, issued, T_{}, F_{}, sA, sB, pB, pA);
+        int j = 1;
+#pragma unroll 1
+        for (; j + 2 < n - 1; j += 2) {            // both steps multiply a K block that is not the split's last
+            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
+            step(j + 1, issued, T_{}, T_{}, sA, sB, pB, pA);
+        }
+        const int rest = n - 1 - j;                // QK^T steps left: 0 (n = 2), 1 or 2
+        if (rest == 2) {
+            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
+            step(j + 1, issued, T_{}, T_{}, sA, sB, pB, pA);
+            step(n - 1, issued, F_{}, T_{}, sB, sA, pA, pB);
+            pv_only(pB);
+        } else if (rest == 1) {
+            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
+            step(n - 1, issued, F_{}, T_{}, sA, sB, pB, pA);
+            pv_only(pA);
+        } else {
+            step(n - 1, issued, F_{}, T_{}, sB, sA, pA, pB);
+            pv_only(pB);
+        }
+    };
+
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {           // (one copy of the pass in the binary)
+        main_pass(attempt == 1);
+        if (attempt == 1) break;
+        if (tid == 0) *redo_flag = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;      // fp16 tops out at 65504: two octaves below it
+        __syncthreads();
+        if (!*redo_flag) break;
+        __syncthreads();
+        max_pass();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last P.V MFMAs are asm statements: retire before the epilogue reads acc
+
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float lt = wave_xor_sum_16_32(lsum[qt]);
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const int m = row0 + qt * 16 + l15;
+        if (m < p.M) {
+            const float lse = lt > 0.f ? mref_lds[qt * 64] * p.scale + __logf(lt) : -INFINITY;
+            const int head = kvh * p.g + m / p.sq;
+            const int rrow = m % p.sq;
+            float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow) * p.H + head) * D + g4 * 4;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
+            if (g4 == 0) p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow] = lse;
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256, 1) void attn_partial_w4_kernel(const AttnK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (p.has_new && blockIdx.x == 0) {            // new-key block: 4 workers x 5 row tiles (one at a time)
+        KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 5, LS_NEW_TARGET>(pk, smem);
+        else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 5, LS_NEW_DRAFT>(pk, smem);
+        else new_block_path<E, 5, LS_NEW_FLASH>(pk, smem);
+    } else {
+        prefix_path_w4<E>(p, smem, (int)blockIdx.x - p.has_new, w);
+    }
+    drain_lds_dma();
+}
+#endif  // LS_WITH_W4
+
 #ifdef LS_WITH_PP
 // ===================== ping-pong prefix path (verification-sized row blocks, 17..24 row tiles) =====================
 // NOT DISPATCHED: a measured negative of round 3, kept behind -DLS_WITH_PP (tools/build_variant.py pp -DLS_WITH_PP, then
@@ -1883,6 +2264,9 @@ int kernel_choice() {       // 0 general, 1 warp-specialised (round 2), 2 ping-p
     static const int choice = [] {
         const char* e = getenv("LS_ATTN_KERNEL");
         if (e && e[0] == 'g') return 0;
+#ifdef LS_WITH_W4
+        if (e && e[0] == 'f') return 3;          // four-wave kernel (round 3, measured negative)
+#endif
 #ifdef LS_WITH_PP
         if (e && e[0] == 'p') return 2;
 #endif
@@ -1897,10 +2281,12 @@ bool ws_eligible(const ls_attn_desc* d) {
     // in the new-key block and every row sees the whole prefix -- hi(r) = min(L, r + sk - sq + 1) = L when sk = L + sq.
     // Only for long prompts: short ones keep the kernel (and the rounding) the goldens were generated against.
     const bool append_chunk = d->causal != 0 && d->new_mode == LS_NEW_FLASH && d->n_app == d->sq && d->kv_len_hint >= 4096;
+    int cap = WS_NEW_CAP;
 #ifdef LS_WITH_PP
-    const int cap = kernel_choice() == 2 ? PP_NEW_CAP : WS_NEW_CAP;
-#else
-    const int cap = WS_NEW_CAP;
+    if (kernel_choice() == 2) cap = PP_NEW_CAP;
+#endif
+#ifdef LS_WITH_W4
+    if (kernel_choice() == 3) cap = W4_NEW_CAP;
 #endif
     return (d->causal == 0 || append_chunk) && d->window_left < 0 && (d->new_mode == LS_NEW_NONE || d->n_new <= cap / 64 * 64);
 }
@@ -1945,6 +2331,17 @@ Cfg pick_cfg(int M, bool ws_ok, bool long_prefix) {
         c.nstages = PP_NEW_CAP / c.tile;            // the new-block workgroup's capacity in this ring
         c.lds = PP_LDS;
         c.pp_extra = tiles - 16;
+    } else
+#endif
+#ifdef LS_WITH_W4
+    if (ws_ok && kernel_choice() == 3 && tiles > 16 && tiles <= 20 && c.row_chunks == 1) {
+        c.ws = 3;                                   // four-wave kernel: 4 waves x 5 row tiles
+        c.qtA = c.qtB = 5; c.RB = 4; c.rbA = 4; c.KS = 1;
+        c.rows_per_chunk = 320;
+        c.threads = 256;
+        c.nd = 4;
+        c.nstages = W4_NEW_CAP / c.tile;
+        c.lds = W4_LDS;
     } else
 #endif
     if (ws2) {
@@ -2067,8 +2464,24 @@ int launch_partial_pp(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
 }
 #endif
 
+#ifdef LS_WITH_W4
+template <typename E>
+int launch_partial_w4(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+    auto fn = attn_partial_w4_kernel<E>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
+    hipLaunchKernelGGL(fn, grid, dim3(c.threads), c.lds, s, k);
+    LS_CHECK_LAUNCH("attn_partial_w4_kernel");
+    return LS_OK;
+}
+#endif
+
 template <typename E>
 int dispatch_partial(const Cfg& c, const AttnK& k, dim3 grid, hipStream_t s) {
+#ifdef LS_WITH_W4
+    if (c.ws == 3) return launch_partial_w4<E>(c, k, grid, s);
+#endif
 #ifdef LS_WITH_PP
     if (c.ws == 2) return launch_partial_pp<E>(c, k, grid, s);
 #endif
@@ -2190,7 +2603,7 @@ int ls_attn_num_parts(const ls_attn_desc* d) {
 const char* ls_attn_kernel_name(const ls_attn_desc* d) {
     if (validate(d)) return "invalid";
     const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), d->kv_len_hint >= 4096);
-    return c.ws == 2 ? "attn_partial_pp_kernel" : c.ws ? "attn_partial_ws_kernel" : "attn_partial_kernel";
+    return c.ws == 3 ? "attn_partial_w4_kernel" : c.ws == 2 ? "attn_partial_pp_kernel" : c.ws ? "attn_partial_ws_kernel" : "attn_partial_kernel";
 }
 
 int ls_attn_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) {

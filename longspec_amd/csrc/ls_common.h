@@ -37,6 +37,28 @@ struct ElemF16 {
     static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    // Register-class-pinned forms for kernels that own the whole 512-entry file (one wave per SIMD): hipcc does not split a
+    // wave's values over the two halves by itself (it spilled 2.8 KB per lane rather than use the accumulator half).
+    //   mfma_acc_a: C/D tied in the ACCUMULATOR half ("a"), A and B in the vector half
+    //   mfma_b_a:   B operand read from the accumulator half, C/D in the vector half
+    // (an MFMA result feeding the next MFMA as C needs no wait state; every other reader is hundreds of instructions away.  The
+    // `s_nop 1` in front: the compiler may have WRITTEN an operand just before the statement -- a copy that assembles a 128-bit
+    // fragment, the zeroing of an accumulator -- and does not know that what follows is an MFMA that needs two wait states
+    // behind a vector write of its operands; without it the results were wrong in a timing-dependent way)
+#if !defined(LS_W4_ASM_MFMA) || defined(LS_W4_BUILTIN_PV)
+    static __device__ __forceinline__ void mfma_acc_a(V8 a, V8 b, f32x4& c) { c = mfma(a, b, c); }
+#else
+    static __device__ __forceinline__ void mfma_acc_a(V8 a, V8 b, f32x4& c) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+#endif
+#if !defined(LS_W4_ASM_MFMA) || defined(LS_W4_BUILTIN_QK)
+    static __device__ __forceinline__ void mfma_b_a(V8 a, V8 b, f32x4& c) { c = mfma(a, b, c); }
+#else
+    static __device__ __forceinline__ void mfma_b_a(V8 a, V8 b, f32x4& c) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+    }
+#endif
     static __device__ __forceinline__ T from_f32(float x) { return (T)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 };
@@ -47,6 +69,20 @@ struct ElemBF16 {
     static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+#if !defined(LS_W4_ASM_MFMA) || defined(LS_W4_BUILTIN_PV)
+    static __device__ __forceinline__ void mfma_acc_a(V8 a, V8 b, f32x4& c) { c = mfma(a, b, c); }
+#else
+    static __device__ __forceinline__ void mfma_acc_a(V8 a, V8 b, f32x4& c) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+#endif
+#if !defined(LS_W4_ASM_MFMA) || defined(LS_W4_BUILTIN_QK)
+    static __device__ __forceinline__ void mfma_b_a(V8 a, V8 b, f32x4& c) { c = mfma(a, b, c); }
+#else
+    static __device__ __forceinline__ void mfma_b_a(V8 a, V8 b, f32x4& c) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+    }
+#endif
     static __device__ __forceinline__ T from_f32(float x) { return (T)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 };
