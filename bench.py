@@ -88,6 +88,32 @@ def algo_bytes_verify(L, H, Hkv, R=74, D=128):
     return 2 * L * Hkv * D * 2 + 2 * R * Hkv * D * 2 + 2 * R * H * D * 2 + R * R // 8
 
 
+def committed_traffic(which, algo_bytes, tol=0.03):
+    """{"traffic", "traffic_source"} of a roofline object: HBM bytes per launch from the newest committed PMC profile of
+    the kernel (profiles/r*_pmc_traffic_<which>_v*.json), only if its launches are this run's launches -- the profile
+    records the algorithmic bytes it was taken at, or (older files) its HBM bytes must lie within 0.9-1.25 x of ours."""
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_traffic_{which}_v*.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                prof = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        hbm = prof.get("hbm_bytes_per_launch")
+        ref = prof.get("algorithmic_bytes_per_launch")
+        if not hbm:
+            continue
+        same = abs(ref - algo_bytes) <= tol * algo_bytes if ref else 0.9 * algo_bytes <= hbm <= 1.25 * algo_bytes
+        if same:
+            return {"traffic": int(hbm), "traffic_source": f"profiles/{os.path.basename(f)} (separate rocprofv3 --pmc passes of "
+                                                             f"this command, per launch; not collected in this run)"}
+    return {"traffic": None}
+
+
 def build_model(cfg, device, agreement, seed):
     from longspec_amd.llama_glide import LlamaGlide
     from longspec_amd.qwen2_glide import Qwen2Glide
@@ -589,14 +615,16 @@ def main():
         # ---- roofline of the kernel north_star names: the hybrid verification attention, stage 1 (this rank's KV shard).
         # achieved = SURVEY 8(d)'s algorithmic bytes of one call / the kernel's average duration, every launch of the timed
         # region's bracketed rounds measured with HIP events recorded by the C ABI on the launch stream.  `traffic` (PMC
-        # HBM bytes) cannot be observed inside this process: it is null here; the rocprofv3 --pmc passes of this same
-        # command are committed under profiles/ (tools/round_profile.sh) and quoted in DESIGN.md.
+        # HBM bytes per launch) cannot be observed inside this process: it is the figure of the separate rocprofv3 --pmc
+        # passes of THIS command (tools/round_profile.sh; FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
+        # prescribes) committed under profiles/ -- quoted only when this run's launch moves the same algorithmic bytes
+        # as the profiled one, null otherwise; `traffic_source` names the file.
         from longspec_amd import ops as _ops2
         mean_us = pool.mean_us()
         ab = algo_bytes_verify(Ls, H, Hkv)
         achieved = ab / (mean_us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": None,
+                           "frac": round(achieved / 8000.0, 4), **committed_traffic("attn", ab),
                            "kernel": f"{_ops2.attn_kernel_name(H // Hkv * 74)} (hybrid tree-verification attention, stage 1: "
                                      f"prefix flash-decoding + tree part)",
                            "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(mean_us, 2), "launches_timed": pool.i,
@@ -607,7 +635,7 @@ def main():
         gs = gpool.stats()
         g_ach = gs["bytes"] / (gs["us"] * 1e-6) / 1e9
         out["roofline_gemm"] = {"bound": "hbm", "achieved": round(g_ach, 2), "peak": 8000.0, "unit": "GB/s",
-                                "frac": round(g_ach / 8000.0, 4), "traffic": None,
+                                "frac": round(g_ach / 8000.0, 4), **committed_traffic("gemm", gs["bytes"] / gs["launches"]),
                                 "kernel": "skinny_gemm_kernel (ls_linear_fwd: q|k|v, o_proj, gate|up+SiLU, down_proj, lm_head of the "
                                           "verify pass and the 5 draft passes)",
                                 "algorithmic_bytes_per_launch": round(gs["bytes"] / gs["launches"]),
