@@ -153,6 +153,17 @@ typedef struct ls_linear_desc {
     const void* rope_sin;
     const void* residual; /* LS_EPI_NONE, optional: [M, sum n[i]] dtype (row stride ldr) added to the ROUNDED projection, */
     int64_t ldr;          /* `residual + mlp(x)` of the decoder layers (llama_glide.py:466); NULL = none                  */
+    /* LlamaRMSNorm (llama.py:36 / qwen2.py:73-90) folded into the projection that consumes it.  `norm_weight` != NULL: x is
+     * the UN-normalised residual stream and the launch multiplies `norm_weight * dtype(x32 * rsqrt(mean(x32^2) + eps))`
+     * instead -- bit-identical to ls_rmsnorm_fwd followed by the plain launch.  The rows' sums of squares come as
+     * `ssq_parts` fp32 partials per row (one per 64 columns of x, column order), written by the launch that produced x:
+     * `ssq_out` != NULL (LS_EPI_NONE, one segment, N % 64 == 0) makes this launch such a producer: [M, N / 64] fp32
+     * partial sums of the squares of the values it stores (after bias and residual).                                  */
+    const void* norm_weight; /* [K] dtype or NULL                                                                        */
+    const float* ssq_in;     /* [M, ssq_parts] fp32                                                                      */
+    float* ssq_out;          /* [M, N / 64] fp32 or NULL                                                                 */
+    int32_t ssq_parts;
+    float norm_eps;
 } ls_linear_desc;
 
 /* Weights are streamed in the MFMA A-operand layout: pack each nn.Linear.weight [N, K] (row-major,

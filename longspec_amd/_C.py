@@ -48,6 +48,8 @@ class LinearDesc(C.Structure):
         ("ldx", C.c_int64), ("ldy", C.c_int64),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
         ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("norm_weight", C.c_void_p), ("ssq_in", C.c_void_p), ("ssq_out", C.c_void_p),
+        ("ssq_parts", C.c_int32), ("norm_eps", C.c_float),
     ]
 
 

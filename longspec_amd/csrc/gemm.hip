@@ -61,6 +61,14 @@ struct GemmK {
     int rope_segs;               // leading segments (q, k) that are rotated; the rest (v) are plain
     const char* residual;        // EPI_NONE: [M, N] dtype added to the rounded output (`residual + mlp(x)`), or null
     long ldr;
+    // RMSNorm folded into the launch (NORM): x is the UN-normalised residual stream; its rows' sums of squares arrive
+    // as `ssq_parts` partials per row (one per 64 columns, written by the launch that produced x), the norm weight is
+    // applied while x is staged.  `ssq_out` (EPI_NONE): this launch is such a producer.
+    const float* ssq_in;         // [M, ssq_parts]
+    int ssq_parts;
+    const char* norm_w;          // [K] dtype
+    float norm_eps;
+    float* ssq_out;              // [M, N / 64] or null
 };
 
 enum { EPI_NONE = 0, EPI_SILU_MUL = 1, EPI_QKV_ROPE = 2 };
@@ -75,7 +83,9 @@ __device__ __forceinline__ float ld_coherent(const float* p) {
 }
 
 // MT = 16-row tiles of x (M <= 16*MT); NT = 16-row weight tiles per workgroup (4: one packed slab, 8: two)
-template <typename E, int MT, int NT, int EPI>
+// NORM: `x` is normalised on the way into LDS -- LlamaRMSNorm's arithmetic (misc.hip::rmsnorm_rows_kernel), with the row
+// sums of squares taken from the producer's 64-column partials in the canonical order (ls_common.h::ssq_*).
+template <typename E, int MT, int NT, int EPI, bool NORM>
 __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_kernel(const GemmK p) {
     using V8 = typename E::V8;
     using V4 = typename E::V4;
@@ -147,16 +157,34 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     unsigned xoff[XL];           // 32-bit byte offsets of this lane's 16 B in each piece (x is far below 4 GB)
 #pragma unroll
     for (int i = 0; i < XL; ++i) xoff[i] = (unsigned)(((long)min(i * 8 + xr_in, p.M - 1) * p.ldx + xslot * 8) * 2);
+    // NORM: behind the last-arriver flag the launch keeps 1 / rms of every row (fp32 [MT * 16]) and the norm weight
+    // (dtype [K]) in LDS; both are read back per piece / per chunk rather than held in registers (the 128-row variant
+    // has none to spare)
+    const float* rs = reinterpret_cast<const float*>(smem + p.flag_off + 16);
+    const char* nwl = smem + p.flag_off + 16 + MT * 64;
+    int x_ch = 0;                // the chunk in `xs`
     auto load_x = [&](int ch) {
         const char* xc = p.x + (long)ch * 128;            // wave-uniform
 #pragma unroll
         for (int i = 0; i < XL; ++i) xs[i] = *reinterpret_cast<const V8*>(xc + xoff[i]);
+        if (NORM) x_ch = ch;
     };
     auto store_x = [&]() {       // slot ^ ((row >> 1) & 7): 16 rows x one slot hit 16 distinct 16 B bank groups
+        V8 nw;
+        if (NORM) nw = *reinterpret_cast<const V8*>(nwl + x_ch * 128 + xslot * 16);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             const int row = i * 8 + xr_in;
-            *reinterpret_cast<V8*>(xlds + row * 128 + ((xslot ^ ((row >> 1) & 7)) << 4)) = xs[i];
+            V8 v = xs[i];
+            if (NORM) {
+                const float rstd = rs[row];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {             // weight * dtype(x32 * rsqrt(mean(x32^2) + eps))
+                    const float n = round_to<E>(E::to_f32(v[e]) * rstd);
+                    v[e] = E::from_f32(E::to_f32(nw[e]) * n);
+                }
+            }
+            *reinterpret_cast<V8*>(xlds + row * 128 + ((xslot ^ ((row >> 1) & 7)) << 4)) = v;
         }
     };
     auto issue_w = [&](int ch, int set) {
@@ -185,6 +213,19 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
 #pragma unroll
     for (int i = 0; i < LAC; ++i)
         if (i < nch) issue_w(ch0 + i, i);
+    if (NORM) {
+        // behind the first weight requests: thread r sums row r's partials in slab order (the canonical order)
+        float* rsw = reinterpret_cast<float*>(smem + p.flag_off + 16);
+        for (int i = tid * 16; i < p.K * 2; i += GEMM_THREADS * 16)
+            *reinterpret_cast<uint4*>(smem + p.flag_off + 16 + MT * 64 + i) = *reinterpret_cast<const uint4*>(p.norm_w + i);
+        if (tid < MT * 16) {
+            const float* src = p.ssq_in + (long)min(tid, p.M - 1) * p.ssq_parts;
+            float tot = 0.f;
+            for (int b = 0; b < p.ssq_parts; ++b) tot += src[b];
+            rsw[tid] = rsqrtf(tot / (float)p.K + p.norm_eps);
+        }
+        __syncthreads();
+    }
     int c = 0;
     // steady state: no control flow inside, so the compiler's in-order vmcnt counts stay exact;
     // sched_barrier(0) keeps the loads of the chunks ahead in front of the MFMAs of the current one
@@ -364,6 +405,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
         } else {
             const int nn = n_tile0 + (h * 4 + wave) * 16 + g4 * 4;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            float tsq[MT];
             if (bias_p != nullptr && nn < n_lim) {
                 const V4 b4 = *reinterpret_cast<const V4*>(bias_p + (long)nn * 2);
 #pragma unroll
@@ -383,6 +425,21 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
                     }
                     *reinterpret_cast<V4*>(p.y + ((long)m * p.ldy + nn) * 2) = o;
                 }
+                // this tile's 16 columns of row m in the canonical order (every lane takes part in the shuffles)
+                if (p.ssq_out != nullptr) tsq[mt] = ssq_tile16(ssq_quad(E::to_f32(o[0]), E::to_f32(o[1]), E::to_f32(o[2]), E::to_f32(o[3])));
+            }
+            if (p.ssq_out != nullptr) {                    // (uniform) the slab's 64 columns: tiles in wave order
+                __syncthreads();                           // the 4-wave reduction no longer reads `red`
+                if (g4 == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) red[wave * (MT * 16) + mt * 16 + l15] = tsq[mt];
+                }
+                __syncthreads();
+                if (tid < MT * 16 && tid < p.M) {
+                    const int R = MT * 16;
+                    p.ssq_out[(long)tid * (p.N >> 6) + slab * NPASS + h] = ssq_slab64(red[tid], red[R + tid], red[2 * R + tid], red[3 * R + tid]);
+                }
+                __syncthreads();
             }
         }
     }
@@ -432,7 +489,7 @@ int num_cus_gemm() {
 }
 
 struct Plan {
-    int MT, NT, nslabs, S, nks, N;
+    int MT, NT, nslabs, S, nks, N, flag_off;
     size_t lds, counter_bytes, part_bytes;
 };
 
@@ -498,6 +555,10 @@ int make_plan(const ls_linear_desc* d, Plan& pl) {
     if (d->ldy < pl.N) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: ldy < N");
     if (d->residual && (d->epilogue != LS_EPI_NONE || d->ldr < pl.N || (d->ldr % 4) != 0))
         LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: residual goes with LS_EPI_NONE, ldr >= N, ldr %% 4 == 0");
+    if (d->norm_weight && (!d->ssq_in || d->ssq_parts < 1))
+        LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: norm_weight needs the rows' sum-of-squares partials (ssq_in, ssq_parts)");
+    if (d->ssq_out && (d->epilogue != LS_EPI_NONE || d->n_seg != 1 || pl.N % 64 != 0))
+        LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear: ssq_out goes with LS_EPI_NONE, one segment, N %% 64 == 0");
     const int groups = (rows + 63) / 64;
     // more than 32 token rows run ONE workgroup per CU (512 registers per wave): give it 128 weight rows when that
     // still fills the chip -- half the x staging traffic, half the workgroups (measured: lm_head 230 -> 209 us)
@@ -508,14 +569,17 @@ int make_plan(const ls_linear_desc* d, Plan& pl) {
     if (pl.NT == 8) pl.S = d->n_splits > 0 ? pl.S : 1;
     if ((size_t)pl.nslabs * 4 > COUNTER_BYTES) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear: N too large (%d slabs)", pl.nslabs);
     pl.lds = (size_t)16 * 4 * pl.MT * 64 * 4 + 16;     // 4 waves x 4 tiles x MT accumulators (>= the 4 x-slabs) + the last-arriver flag
+    pl.flag_off = (int)pl.lds - 16;
+    if (d->norm_weight) pl.lds += (size_t)pl.MT * 64 + (size_t)d->K * 2;      // + 1 / rms of the rows + the norm weight
+    if (pl.lds > 160 * 1024) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_linear: K=%d too large for a folded norm", d->K);
     pl.counter_bytes = COUNTER_BYTES;
     pl.part_bytes = pl.S > 1 ? (size_t)pl.S * pl.nslabs * pl.NT * pl.MT * 4 * 64 * 4 : 0;
     return LS_OK;
 }
 
-template <typename E, int MT, int NT, int EPI>
-int launch(const GemmK& k, const Plan& pl, hipStream_t s) {
-    auto kern = skinny_gemm_kernel<E, MT, NT, EPI>;
+template <typename E, int MT, int NT, int EPI, bool NORM>
+int launch_n(const GemmK& k, const Plan& pl, hipStream_t s) {
+    auto kern = skinny_gemm_kernel<E, MT, NT, EPI, NORM>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -524,6 +588,11 @@ int launch(const GemmK& k, const Plan& pl, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(pl.nslabs, pl.S), dim3(GEMM_THREADS), pl.lds, s, k);
     LS_CHECK_LAUNCH("skinny_gemm_kernel");
     return LS_OK;
+}
+
+template <typename E, int MT, int NT, int EPI>
+int launch(const GemmK& k, const Plan& pl, hipStream_t s) {
+    return k.norm_w != nullptr ? launch_n<E, MT, NT, EPI, true>(k, pl, s) : launch_n<E, MT, NT, EPI, false>(k, pl, s);
 }
 
 template <typename E, int EPI>
@@ -614,12 +683,17 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
     k.nks = pl.nks;
     k.S = pl.S;
     k.nslabs = pl.nslabs;
-    k.flag_off = (int)pl.lds - 16;
+    k.flag_off = pl.flag_off;
     k.rope_cos = static_cast<const char*>(d->rope_cos);
     k.rope_sin = static_cast<const char*>(d->rope_sin);
     k.rope_segs = d->n_seg < 2 ? d->n_seg : 2;
     k.residual = static_cast<const char*>(d->residual);
     k.ldr = d->ldr;
+    k.norm_w = static_cast<const char*>(d->norm_weight);
+    k.norm_eps = d->norm_eps;
+    k.ssq_in = d->ssq_in;
+    k.ssq_parts = d->ssq_parts;
+    k.ssq_out = d->ssq_out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     if (d->dtype == LS_F16)

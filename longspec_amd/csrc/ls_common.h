@@ -87,6 +87,20 @@ struct ElemBF16 {
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 };
 
+// ---- canonical order of a row's sum of squares (RMSNorm), shared by misc.hip::rmsnorm_rows_kernel and the producers /
+// consumers of gemm.hip so that a norm folded into the next projection is bit-identical to the stand-alone kernel:
+//   quad  = ((x0^2 + x1^2) + x2^2) + x3^2                 4 consecutive columns (fp32, no contraction)
+//   tile  = (quad0 + quad1) + (quad2 + quad3)             16 columns
+//   slab  = ((tile0 + tile1) + tile2) + tile3             64 columns
+//   row   = (((slab0 + slab1) + slab2) + ...)             in column order
+__device__ __forceinline__ float ssq_quad(float a, float b, float c, float d) { return ((a * a + b * b) + c * c) + d * d; }
+// MFMA accumulator layout: the quads of a row's 16 columns sit in lanes l, l+16, l+32, l+48
+__device__ __forceinline__ float ssq_tile16(float quad) {
+    const float pair = quad + __shfl_xor(quad, 16);        // (q0 + q1) in lanes of g4 = 0, 1; (q2 + q3) in g4 = 2, 3
+    return pair + __shfl_xor(pair, 32);                    // commutative: the same bits in all four lanes
+}
+__device__ __forceinline__ float ssq_slab64(float t0, float t1, float t2, float t3) { return ((t0 + t1) + t2) + t3; }
+
 // round-trip through the storage type (one rounding), as `tensor.to(dtype)` does
 template <typename E>
 __device__ __forceinline__ float round_to(float x) {

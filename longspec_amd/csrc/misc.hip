@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const typename E::T* __res
 // Short-chain variant for the decode passes (<= 80 rows, a launch is pure latency): one 8-element chunk per thread
 // (NCH of them for hidden > 8192), every global load -- x, residual AND weight -- issued before the first use,
 // the row kept in registers, one barrier.
-template <typename E, int NCH>
+// CANON (hidden a multiple of 64): the sum of squares is taken in the canonical order of ls_common.h (quads, 16-column
+// tiles, 64-column slabs, slabs in column order) -- the order in which the projections of gemm.hip produce and consume it, so
+// that a norm folded into the next projection and this kernel give the same bits.
+template <typename E, int NCH, bool CANON>
 __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T* __restrict__ x,
                                                             const typename E::T* __restrict__ res,
                                                             const typename E::T* __restrict__ wgt, typename E::T* __restrict__ y,
@@ -85,29 +88,47 @@ __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T*
             w8[c] = *reinterpret_cast<const typename E::V8*>(wgt + i);
         }
     }
+    __shared__ float slab_s[CANON ? 512 : 1];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * T + tid) * 8;
+        float s8 = 0.f;
         if (i < hidden) {
             if (res) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[c][e] = E::from_f32(E::to_f32(r[c][e]) + E::to_f32(v[c][e]));
                 if (sum_out) *reinterpret_cast<typename E::V8*>(sum_out + base + i) = v[c];
             }
+            if (CANON) {
+                s8 = ssq_quad(E::to_f32(v[c][0]), E::to_f32(v[c][1]), E::to_f32(v[c][2]), E::to_f32(v[c][3])) +
+                     ssq_quad(E::to_f32(v[c][4]), E::to_f32(v[c][5]), E::to_f32(v[c][6]), E::to_f32(v[c][7]));
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = E::to_f32(v[c][e]);
-                ss += f * f;
+                for (int e = 0; e < 8; ++e) {
+                    const float f = E::to_f32(v[c][e]);
+                    ss += f * f;
+                }
             }
         }
+        if (CANON) {             // 2 threads = a 16-column tile, 8 threads = a 64-column slab (whole slabs are valid or not)
+            const float tile = s8 + __shfl_xor(s8, 1);
+            const int b8 = (tid & 63) & ~7;
+            const float slab = ssq_slab64(__shfl(tile, b8), __shfl(tile, b8 + 2), __shfl(tile, b8 + 4), __shfl(tile, b8 + 6));
+            if ((tid & 7) == 0 && i < hidden) slab_s[i >> 6] = slab;
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
     float tot = 0.f;
-    for (int wv = 0; wv < (T >> 6); ++wv) tot += red[wv];
+    if (CANON) {
+        __syncthreads();
+        for (int b = 0; b < (hidden >> 6); ++b) tot += slab_s[b];
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        for (int wv = 0; wv < (T >> 6); ++wv) tot += red[wv];
+    }
     const float rs = rsqrtf(tot / (float)hidden + eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -209,16 +230,20 @@ int ls_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void
             T = (((chunks + nch - 1) / nch + 63) / 64) * 64;
         }
 #define LS_NORM_ROWS(EL, TY, N)                                                                                           \
-    hipLaunchKernelGGL((rmsnorm_rows_kernel<EL, N>), dim3(rows), dim3(T), 0, s, (const TY*)x, (const TY*)residual,        \
-                       (const TY*)weight, (TY*)y, (TY*)sum_out, hidden, eps)
+    if (hidden % 64 == 0)                                                                                                 \
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<EL, N, true>), dim3(rows), dim3(T), 0, s, (const TY*)x,                   \
+                           (const TY*)residual, (const TY*)weight, (TY*)y, (TY*)sum_out, hidden, eps);                    \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((rmsnorm_rows_kernel<EL, N, false>), dim3(rows), dim3(T), 0, s, (const TY*)x,                  \
+                           (const TY*)residual, (const TY*)weight, (TY*)y, (TY*)sum_out, hidden, eps)
         if (dtype == LS_F16) {
-            if (nch == 1) LS_NORM_ROWS(ElemF16, _Float16, 1);
-            else if (nch == 2) LS_NORM_ROWS(ElemF16, _Float16, 2);
-            else LS_NORM_ROWS(ElemF16, _Float16, 4);
+            if (nch == 1) { LS_NORM_ROWS(ElemF16, _Float16, 1); }
+            else if (nch == 2) { LS_NORM_ROWS(ElemF16, _Float16, 2); }
+            else { LS_NORM_ROWS(ElemF16, _Float16, 4); }
         } else {
-            if (nch == 1) LS_NORM_ROWS(ElemBF16, __bf16, 1);
-            else if (nch == 2) LS_NORM_ROWS(ElemBF16, __bf16, 2);
-            else LS_NORM_ROWS(ElemBF16, __bf16, 4);
+            if (nch == 1) { LS_NORM_ROWS(ElemBF16, __bf16, 1); }
+            else if (nch == 2) { LS_NORM_ROWS(ElemBF16, __bf16, 2); }
+            else { LS_NORM_ROWS(ElemBF16, __bf16, 4); }
         }
 #undef LS_NORM_ROWS
         LS_CHECK_LAUNCH("rmsnorm_rows_kernel");

@@ -254,7 +254,18 @@ def set_linear_timing(hook):
     _linear_timing = hook
 
 
-def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None, residual=None):
+class NormFold:
+    """An RMSNorm that has not been applied yet: ``h`` is the un-normalised residual stream, ``ssq`` [rows, hidden / 64]
+    the fp32 partial sums of squares of its rows (written by the projection that produced ``h``, ``linear(...,
+    ssq_out=True)``), ``weight`` / ``eps`` the norm's parameters.  The projections take it as ``norm=`` together with
+    ``x = h`` and normalise on the way in -- bit-identical to ``rmsnorm`` followed by the plain call."""
+    __slots__ = ("weight", "eps", "ssq")
+
+    def __init__(self, weight, eps, ssq):
+        self.weight, self.eps, self.ssq = weight, float(eps), ssq
+
+
+def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None, residual=None, norm=None, ssq_out=False):
     _dev(x)
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -300,13 +311,26 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=Non
             if t.dtype != x.dtype or not t.is_contiguous() or t.numel() != M * 128:
                 raise ValueError("linear_qkv_rope: cos/sin must be contiguous [rows, 128] tables of x's dtype")
         d.rope_cos, d.rope_sin = cos.data_ptr(), sin.data_ptr()
+    ssq = None
+    if norm is not None:
+        _dev(norm.weight, norm.ssq)
+        if (norm.weight.dtype != x.dtype or norm.weight.numel() != K or not norm.weight.is_contiguous()
+                or norm.ssq.dtype != torch.float32 or norm.ssq.dim() != 2 or norm.ssq.shape[0] != M or not norm.ssq.is_contiguous()):
+            raise ValueError("linear: norm = NormFold(weight [K] of x's dtype, eps, ssq fp32 [rows, parts] contiguous)")
+        d.norm_weight, d.norm_eps = norm.weight.data_ptr(), norm.eps
+        d.ssq_in, d.ssq_parts = norm.ssq.data_ptr(), norm.ssq.shape[1]
+    if ssq_out:
+        if epilogue != _C.LS_EPI_NONE or len(weights) != 1 or n_out % 64:
+            raise ValueError("linear: ssq_out goes with a single plain projection whose N is a multiple of 64")
+        ssq = torch.empty((M, n_out // 64), dtype=torch.float32, device=x.device)
+        d.ssq_out = ssq.data_ptr()
     if timing is None and _linear_timing is not None:
         rows_w = sum(w.n for w in weights) * (2 if epilogue == _C.LS_EPI_SILU_MUL else 1)
         timing = _linear_timing((rows_w * K + M * K + M * n_out) * x.element_size())
     if timing is not None:          # (torch.cuda.Event, torch.cuda.Event), both already created by a record()
         d.ev_start, d.ev_stop = timing[0].cuda_event, timing[1].cuda_event
     lib = _C.load()
-    key = (M, K, d.n[0], d.n[1], d.n[2], epilogue, n_splits, d.dtype)
+    key = (M, K, d.n[0], d.n[1], d.n[2], epilogue, n_splits, d.dtype, norm is not None)
     need = _linear_need.get(key)
     if need is None:
         need = lib.ls_linear_workspace_bytes(C.byref(d))
@@ -316,23 +340,27 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=Non
     stream = _stream()
     ws = _gemm_ws.get(x.device, need, stream)
     _C.check(lib.ls_linear_fwd(C.byref(d), ws.data_ptr(), ws.numel(), stream), "ls_linear_fwd")
-    return y
+    return (y, ssq) if ssq_out else y
 
 
 def linear(x: torch.Tensor, weight: PackedWeight, bias: Optional[torch.Tensor] = None, n_splits: int = 0, timing=None,
-           residual: Optional[torch.Tensor] = None):
+           residual: Optional[torch.Tensor] = None, norm: Optional[NormFold] = None, ssq_out: bool = False):
     """``F.linear(x, weight, bias)`` for M <= 80 token rows: ``[..., K] -> [..., N]``; with ``residual`` [..., N]:
-    ``residual + F.linear(...)`` (the projection rounded first, as the two separate operators do)."""
-    y = _linear_call(x, [weight], [bias], _C.LS_EPI_NONE, n_splits, timing, residual=residual)
-    return y.view(*x.shape[:-1], weight.n)
+    ``residual + F.linear(...)`` (the projection rounded first, as the two separate operators do).
+    ``norm``: ``F.linear(rmsnorm(x), ...)`` (see NormFold).  ``ssq_out``: returns ``(y, ssq)`` with the partial sums of
+    squares of y's rows, the input of the NormFold of the projection that consumes y."""
+    out = _linear_call(x, [weight], [bias], _C.LS_EPI_NONE, n_splits, timing, residual=residual, norm=norm, ssq_out=ssq_out)
+    if ssq_out:
+        return out[0].view(*x.shape[:-1], weight.n), out[1]
+    return out.view(*x.shape[:-1], weight.n)
 
 
-def linear_multi(x: torch.Tensor, weights, biases=None, n_splits: int = 0, timing=None):
+def linear_multi(x: torch.Tensor, weights, biases=None, n_splits: int = 0, timing=None, norm: Optional[NormFold] = None):
     """Several linears of the same input in ONE launch (q|k|v): returns views ``[..., n_i]`` of one
     ``[M, sum n_i]`` buffer."""
     weights = list(weights)
     biases = list(biases) if biases is not None else [None] * len(weights)
-    y = _linear_call(x, weights, biases, _C.LS_EPI_NONE, n_splits, timing)
+    y = _linear_call(x, weights, biases, _C.LS_EPI_NONE, n_splits, timing, norm=norm)
     outs, o = [], 0
     for w in weights:
         outs.append(y[:, o:o + w.n].unflatten(0, x.shape[:-1]))
@@ -340,13 +368,14 @@ def linear_multi(x: torch.Tensor, weights, biases=None, n_splits: int = 0, timin
     return outs
 
 
-def linear_qkv_rope(x: torch.Tensor, weights, biases, cos: torch.Tensor, sin: torch.Tensor, n_splits: int = 0, timing=None):
+def linear_qkv_rope(x: torch.Tensor, weights, biases, cos: torch.Tensor, sin: torch.Tensor, n_splits: int = 0, timing=None,
+                    norm: Optional[NormFold] = None):
     """``apply_rotary_pos_emb(q_proj(x), k_proj(x), cos, sin)`` and ``v_proj(x)`` (``llama.py:371-378``) in ONE launch:
     the rotation runs in the projection's epilogue on the rounded outputs, with the roundings of ``rope_apply_``.
     ``weights`` = [q] or [q, k] or [q, k, v] (q, k packed with ``rope=True``); cos/sin [rows, 128]."""
     weights = list(weights)
     biases = list(biases) if biases is not None else [None] * len(weights)
-    y = _linear_call(x, weights, biases, _C.LS_EPI_QKV_ROPE, n_splits, timing, rope=(cos, sin))
+    y = _linear_call(x, weights, biases, _C.LS_EPI_QKV_ROPE, n_splits, timing, rope=(cos, sin), norm=norm)
     outs, o = [], 0
     for w in weights:
         outs.append(y[:, o:o + w.n].unflatten(0, x.shape[:-1]))
@@ -354,10 +383,10 @@ def linear_qkv_rope(x: torch.Tensor, weights, biases, cos: torch.Tensor, sin: to
     return outs
 
 
-def mlp_gate_up(x: torch.Tensor, gate_up: PackedWeight, n_splits: int = 0, timing=None):
+def mlp_gate_up(x: torch.Tensor, gate_up: PackedWeight, n_splits: int = 0, timing=None, norm: Optional[NormFold] = None):
     """``act_fn(gate_proj(x)) * up_proj(x)`` (SiLU) with the reference's roundings: both projections and the
     activation are rounded to the storage dtype before the product (qwen2.py:229).  ``gate_up`` = pack_gate_up(...)."""
-    y = _linear_call(x, [gate_up], None, _C.LS_EPI_SILU_MUL, n_splits, timing)
+    y = _linear_call(x, [gate_up], None, _C.LS_EPI_SILU_MUL, n_splits, timing, norm=norm)
     return y.view(*x.shape[:-1], gate_up.n)
 
 

@@ -61,11 +61,11 @@ def test_linear_desc_layout_matches_header():
         if not tail:
             continue
         tail = re.sub(r"\[\d+\]", "", tail)
-        for kw in ("const", "void", "int32_t", "int64_t", "*"):
+        for kw in ("const", "void", "int32_t", "int64_t", "float", "*"):
             tail = tail.replace(kw, " ")
         fields += [f.strip() for f in tail.split(",") if f.strip()]
     assert fields == [f[0] for f in _C.LinearDesc._fields_]
-    assert ctypes.sizeof(_C.LinearDesc) == (1 + 3 + 3 + 1 + 2) * 8 + (2 + 3 + 4) * 4 + 4 + 2 * 8 + 2 * 8 + 2 * 8
+    assert ctypes.sizeof(_C.LinearDesc) == (1 + 3 + 3 + 1 + 2) * 8 + (2 + 3 + 4) * 4 + 4 + 2 * 8 + 2 * 8 + 2 * 8 + 3 * 8 + 2 * 4
 
 
 def test_ops_refuse_cpu_tensors():

@@ -248,3 +248,57 @@ def test_decode_linear_module_repacks_after_weight_update():
     _check(lin(x).cpu(), ref_ops.linear(x.cpu(), lin.weight.detach().cpu(), lin.bias.detach().cpu()), 1e-5)
     big = _mk((200, 256), 92).cuda()                      # prefill-shaped: library GEMM
     assert lin(big).shape == (200, 512)
+
+
+@pytest.mark.parametrize("hidden,inter", [(4096, 14336), (5120, 13824), (256, 512), (896, 1024)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("M", [1, 7, 16, 30, 74, 80])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_rmsnorm_folded_into_the_projections(hidden, inter, M, dtype):
+    """The producer side (`ssq_out`: the partial sums of squares of what o_proj / down_proj store, residual included) and
+    the consumer side (`norm=NormFold`: q|k|v with the rotary epilogue, gate|up + SiLU, a plain projection) of the folded
+    LlamaRMSNorm against the chain it replaces -- `rmsnorm(residual + y)` then the plain launch --, bit for bit: the sum of
+    squares is taken in one canonical order by both (csrc/ls_common.h)."""
+    from longspec_amd import ops
+    eps = 1e-5
+    x = _mk((1, M, inter), 1, dtype=dtype).cuda()
+    res = _mk((1, M, hidden), 2, 3.0, dtype=dtype).cuda()
+    w_down = ops.pack_weight(_mk((hidden, inter), 3, inter ** -0.5, dtype=dtype).cuda())
+    nw = (1.0 + 0.1 * _mk((hidden,), 4)).to(dtype).cuda()
+    # producer: residual + down_proj(x) with the row statistics on the side
+    h_ref = ops.linear(x, w_down, None, residual=res)
+    h, ssq = ops.linear(x, w_down, None, residual=res, ssq_out=True)
+    assert torch.equal(h, h_ref) and ssq.shape == (M, hidden // 64)
+    want_ssq = h.float().reshape(M, hidden // 64, 64).pow(2).sum(-1)
+    assert torch.allclose(ssq, want_ssq, rtol=1e-5, atol=0)
+    hn = ops.rmsnorm(h, nw, eps)                                   # the stand-alone kernel, same canonical order
+    fold = ops.NormFold(nw, eps, ssq)
+    # consumer 1: gate|up + SiLU
+    gu = ops.pack_gate_up(_mk((inter, hidden), 5, hidden ** -0.5, dtype=dtype).cuda(),
+                          _mk((inter, hidden), 6, hidden ** -0.5, dtype=dtype).cuda())
+    assert torch.equal(ops.mlp_gate_up(h, gu, norm=fold), ops.mlp_gate_up(hn, gu))
+    # consumer 2: a plain projection with bias (lm_head-like, ragged N), and again as a producer
+    N2 = 1000 if hidden < 1024 else 3000
+    w2 = ops.pack_weight(_mk((N2, hidden), 7, hidden ** -0.5, dtype=dtype).cuda())
+    b2 = _mk((N2,), 8, 0.3, dtype=dtype).cuda()
+    assert torch.equal(ops.linear(h, w2, b2, norm=fold), ops.linear(hn, w2, b2))
+    # consumer 3: q|k|v with the rotary epilogue (heads x 128 columns)
+    if hidden % 128 == 0:
+        Nq, Nkv = hidden, max(128, hidden // 4 // 128 * 128)
+        ws = [_mk((n, hidden), 9 + i, hidden ** -0.5, dtype=dtype).cuda() for i, n in enumerate((Nq, Nkv, Nkv))]
+        bs = [_mk((n,), 12 + i, 0.5, dtype=dtype).cuda() for i, n in enumerate((Nq, Nkv, Nkv))]
+        pos = torch.arange(500, 500 + M)[None]
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, 128, 2).float() / 128))
+        cos, sin = ops.rope_cos_sin(pos.cuda(), inv_freq.cuda(), 1.0, dtype)
+        packed = [ops.pack_weight(w, rope=i < 2) for i, w in enumerate(ws)]
+        for a, b in zip(ops.linear_qkv_rope(h, packed, bs, cos, sin, norm=fold), ops.linear_qkv_rope(hn, packed, bs, cos, sin)):
+            assert torch.equal(a, b)
+        plain = [ops.pack_weight(w) for w in ws]
+        for a, b in zip(ops.linear_multi(h, plain, bs, norm=fold), ops.linear_multi(hn, plain, bs)):
+            assert torch.equal(a, b)
+    # a second norm of the same stream through the residual path of the stand-alone kernel
+    y2 = ops.linear(x, w_down, None)
+    hn2, h2 = ops.rmsnorm(y2, nw, eps, residual=res)
+    assert torch.equal(h2, h) and torch.equal(hn2, hn)
+    with pytest.raises(ValueError):
+        ops.mlp_gate_up(h, gu, norm=ops.NormFold(nw[:-8].contiguous(), eps, ssq))
