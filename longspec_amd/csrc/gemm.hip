@@ -219,9 +219,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
         for (int i = tid * 16; i < p.K * 2; i += GEMM_THREADS * 16)
             *reinterpret_cast<uint4*>(smem + p.flag_off + 16 + MT * 64 + i) = *reinterpret_cast<const uint4*>(p.norm_w + i);
         if (tid < MT * 16) {
-            const float* src = p.ssq_in + (long)min(tid, p.M - 1) * p.ssq_parts;
-            float tot = 0.f;
-            for (int b = 0; b < p.ssq_parts; ++b) tot += src[b];
+            const float tot = ssq_row(p.ssq_in + (long)min(tid, p.M - 1) * p.ssq_parts, p.ssq_parts);
             rsw[tid] = rsqrtf(tot / (float)p.K + p.norm_eps);
         }
         __syncthreads();

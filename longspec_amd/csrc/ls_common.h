@@ -92,7 +92,8 @@ struct ElemBF16 {
 //   quad  = ((x0^2 + x1^2) + x2^2) + x3^2                 4 consecutive columns (fp32, no contraction)
 //   tile  = (quad0 + quad1) + (quad2 + quad3)             16 columns
 //   slab  = ((tile0 + tile1) + tile2) + tile3             64 columns
-//   row   = (((slab0 + slab1) + slab2) + ...)             in column order
+//   group = ((((slab0 + slab1) + slab2) + ...) + slab7)    8 consecutive slabs = 512 columns (the last group may be short)
+//   row   = (((group0 + group1) + group2) + ...)           in column order
 __device__ __forceinline__ float ssq_quad(float a, float b, float c, float d) { return ((a * a + b * b) + c * c) + d * d; }
 // MFMA accumulator layout: the quads of a row's 16 columns sit in lanes l, l+16, l+32, l+48
 __device__ __forceinline__ float ssq_tile16(float quad) {
@@ -100,6 +101,28 @@ __device__ __forceinline__ float ssq_tile16(float quad) {
     return pair + __shfl_xor(pair, 32);                    // commutative: the same bits in all four lanes
 }
 __device__ __forceinline__ float ssq_slab64(float t0, float t1, float t2, float t3) { return ((t0 + t1) + t2) + t3; }
+// `slabs[0 .. n)`: a row's slab sums in column order (global or LDS); eight independent chains, then one
+__device__ __forceinline__ float ssq_row(const float* slabs, int n) {
+    float tot = 0.f;
+    int b = 0;
+    for (; b + 64 <= n; b += 64) {                          // 8 whole groups at a time
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g[j] = slabs[b + 8 * j];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) g[j] += slabs[b + 8 * j + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot += g[j];
+    }
+    for (; b < n; b += 8) {
+        float g = slabs[b];
+        for (int i = 1; i < 8 && b + i < n; ++i) g += slabs[b + i];
+        tot += g;
+    }
+    return tot;
+}
 
 // round-trip through the storage type (one rounding), as `tensor.to(dtype)` does
 template <typename E>

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const typename E::T* __res
 // (NCH of them for hidden > 8192), every global load -- x, residual AND weight -- issued before the first use,
 // the row kept in registers, one barrier.
 // CANON (hidden a multiple of 64): the sum of squares is taken in the canonical order of ls_common.h (quads, 16-column
-// tiles, 64-column slabs, slabs in column order) -- the order in which the projections of gemm.hip produce and consume it, so
+// tiles, 64-column slabs, groups of eight slabs in column order) -- the order in which the projections of gemm.hip produce and consume it, so
 // that a norm folded into the next projection and this kernel give the same bits.
 template <typename E, int NCH, bool CANON>
 __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T* __restrict__ x,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T*
     float tot = 0.f;
     if (CANON) {
         __syncthreads();
-        for (int b = 0; b < (hidden >> 6); ++b) tot += slab_s[b];
+        tot = ssq_row(slab_s, hidden >> 6);
     } else {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
