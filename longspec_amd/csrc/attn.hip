@@ -2383,6 +2383,11 @@ int pick_splits(const ls_attn_desc* d, const Cfg& c) {
     if (target < 1) target = 1;
     int s = target < tiles ? target : tiles;
     if (s > 512) s = 512;
+    // Splits whose first rows lie a multiple of 512 cache rows (1 MB at 8 kv heads) apart walk the same HBM channels in step
+    // all launch long: 32 splits of a 131072-row prefix (4096 rows each) take 116 us per call, 31 splits 106.5
+    // (tools/sweep_cross_attn_128k.py).  Calls with a new-key block have an odd split count already (one CU per kv head
+    // goes to that block); the others give up a split for an odd stride.
+    while (s > 1 && tiles > s && (((tiles + s - 1) / s) * tile) % 512 == 0) --s;
     return s;
 }
 
