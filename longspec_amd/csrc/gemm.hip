@@ -41,6 +41,14 @@
 namespace {
 
 constexpr int GEMM_THREADS = 256;
+// Bytes of padding between the 64-row groups of a packed weight (experiment hook, 0 in the product).  The groups lie
+// nks * 4 KB apart -- 512 KB for K = 4096 -- and the workgroups of a launch walk them at the same pace; an 8 MB stride
+// between the splits costs the attention 9 % (tools/sweep_cross_attn_128k.py).  Here it does not: 256 B, 4 KB and 36 KB of
+// padding all measured within +-2 us of the unpadded layout on every projection (profiles/r3_gemm_group_pad.txt).
+#ifndef LS_GEMM_GROUP_PAD
+#define LS_GEMM_GROUP_PAD 0
+#endif
+constexpr long GROUP_PAD = LS_GEMM_GROUP_PAD;
 constexpr int COUNTER_BYTES = 64 * 1024;   // fixed counter region at the head of the workspace (16384 slabs)
 
 struct GemmK {
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     int n_lim;                   // end of the valid output columns of this slab's segment (global column)
     int n_tile0;                 // global output column of tile 0
     int seg_base = 0, seg = 0;
-    const long group_b = (long)p.nks * 4096;
+    const long group_b = (long)p.nks * 4096 + GROUP_PAD;
     {
         const int row0 = slab * NT * 16;                 // first packed row of the workgroup (global over segments)
         if (EPI != EPI_SILU_MUL) {
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const uint16_t* __rest
         }
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < N) v = *reinterpret_cast<const uint4*>(src + (long)row * K + ks * 32 + (l >> 4) * 8);
-        *reinterpret_cast<uint4*>(out + blk * 512 + l * 8) = v;
+        *reinterpret_cast<uint4*>(out + blk * 512 + (long)g * (GROUP_PAD / 2) + l * 8) = v;
     }
 }
 
@@ -617,7 +625,7 @@ extern "C" {
 
 size_t ls_linear_packed_bytes(int N, int K) {
     if (N < 1 || K < 32 || K % 32 != 0) return 0;
-    return (size_t)((N + 63) / 64) * 64 * (size_t)K * 2;
+    return (size_t)((N + 63) / 64) * (64 * (size_t)K * 2 + (size_t)GROUP_PAD);
 }
 
 static int pack_impl(const void* w, const void* w_up, void* packed, int N, int K, int dtype, void* stream, const char* what,
