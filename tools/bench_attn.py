@@ -33,6 +33,9 @@ def main():
                     help="between two attention calls stream MB megabytes through a copy kernel, the way a decode round puts ~190 us "
                          "of weight-streaming GEMMs between them (436 MB per layer for Llama-3-8B): the attention kernel then runs at "
                          "the clock it gets inside a round, not at the one a back-to-back loop of itself is throttled to")
+    ap.add_argument("--kv-gap", type=int, default=None, metavar="BYTES",
+                    help="carve K and V out of ONE buffer, V starting at (K's size rounded up to 2 MB) + BYTES: does the distance "
+                         "between the two streams a workgroup reads in step matter to the HBM channels?")
     args = ap.parse_args()
     dev = "cuda"
     for L in args.L:
@@ -43,6 +46,15 @@ def main():
         gen = torch.Generator(device="cpu").manual_seed(1235)
         kc = torch.randn(1, L + 512, Hkv, 128, generator=gen).to(torch.float16).to(dev)
         vc = torch.randn(1, L + 512, Hkv, 128, generator=gen).to(torch.float16).to(dev)
+        if args.kv_gap is not None:
+            nb = kc.numel() * 2
+            v_at = (nb + (2 << 20) - 1) // (2 << 20) * (2 << 20) + args.kv_gap
+            buf = torch.empty(v_at + nb, dtype=torch.uint8, device=dev)
+            k2 = buf[:nb].view(torch.float16).view(kc.shape)
+            v2 = buf[v_at:v_at + nb].view(torch.float16).view(vc.shape)
+            k2.copy_(kc)
+            v2.copy_(vc)
+            kc, vc = k2, v2
         q, k, v = q.to(dev), k.to(dev), v.to(dev)
         if args.zeros:
             for t in (q, k, v, kc, vc):
@@ -93,7 +105,7 @@ def main():
             us = s.elapsed_time(e) * 1e3 / args.iters
         by = algo_bytes(L, H, Hkv, R=args.sq)
         flops = 4 * args.sq * H * 128 * L
-        print(json.dumps({"mode": args.mode, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
+        print(json.dumps({"mode": args.mode, "kv_gap": args.kv_gap, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
                           "algo_GBps": round(by / us / 1e3, 1), "frac_of_8TBps": round(by / us / 1e3 / 8000, 4),
                           "TFLOPs": round(flops / us / 1e6, 1)}))
 
