@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--kv-gap", type=int, default=None, metavar="BYTES",
                     help="carve K and V out of ONE buffer, V starting at (K's size rounded up to 2 MB) + BYTES: does the distance "
                          "between the two streams a workgroup reads in step matter to the HBM channels?")
+    ap.add_argument("--head-major", action="store_true",
+                    help="K/V stored [b, Hkv, S, 128] and passed as the permuted [b, S, Hkv, 128] view: every workgroup streams one "
+                         "contiguous region instead of 256 B out of every 2 KB row")
     args = ap.parse_args()
     dev = "cuda"
     for L in args.L:
@@ -55,6 +58,9 @@ def main():
             k2.copy_(kc)
             v2.copy_(vc)
             kc, vc = k2, v2
+        if args.head_major:
+            kc = kc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+            vc = vc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
         q, k, v = q.to(dev), k.to(dev), v.to(dev)
         if args.zeros:
             for t in (q, k, v, kc, vc):
@@ -105,7 +111,7 @@ def main():
             us = s.elapsed_time(e) * 1e3 / args.iters
         by = algo_bytes(L, H, Hkv, R=args.sq)
         flops = 4 * args.sq * H * 128 * L
-        print(json.dumps({"mode": args.mode, "kv_gap": args.kv_gap, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
+        print(json.dumps({"mode": args.mode, "kv_gap": args.kv_gap, "head_major": args.head_major, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
                           "algo_GBps": round(by / us / 1e3, 1), "frac_of_8TBps": round(by / us / 1e3 / 8000, 4),
                           "TFLOPs": round(flops / us / 1e6, 1)}))
 
