@@ -539,11 +539,14 @@ def test_append_attention_large_batch_is_batch_independent(ops, n_splits):
 # BASELINE sizes: the whole hybrid call against the oracle, then size-independent properties
 # --------------------------------------------------------------------------- #
 FULL_SIZE = [  # (H, Hkv, L, last_layer, dtype): BASELINE.json's head layouts at their own prefix lengths
+    (32, 32, 4096, False, torch.float16),         # configs[0]: Vicuna-7B (MHA), the reference's own CPU-runnable case
     (32, 8, 16384, False, torch.float16),         # configs[1]: Llama-3-8B, 16k
+    (32, 8, 16384 + 37, True, torch.float16),     #   SURVEY 8(d)'s ragged length, last layer
     (32, 8, 131072, False, torch.float16),        # configs[2]: Llama-3-8B, 128k (the metric's size)
     (32, 8, 131072 - 21, True, torch.float16),    #   ragged length, last layer (pre-scaled q)
     (40, 40, 8192, False, torch.float16),         # configs[3]: LongChat-13B (MHA), GovReport-length prefix
     (40, 8, 32768, False, torch.bfloat16),        # configs[4]: QwQ-32B, bf16, 32k prefix
+    (40, 8, 52000, True, torch.bfloat16),         #   ... grown to 52k by its 20000-token generations, last layer
 ]
 
 
