@@ -633,3 +633,32 @@ def test_full_size_properties(ops, L):
         ref = torch.matmul(torch.softmax(s, -1), vh).permute(1, 0, 2)
         assert_close_rel(o_full[0, :, h0:h0 + 8], ref, ulps=2.0, what=f"dense fp32 soft-max L={L} heads {h0}..")
         assert (lse_full[0, h0:h0 + 8] - torch.logsumexp(s, -1)).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("sq,causal", [(16, False), (4, False), (3, True), (1, True)],
+                         ids=["tree_level_16", "tree_level_4", "step0_3_accepted_causal", "one_row"])
+def test_full_size_draft_cross_attention(ops, sq, causal):
+    """The draft layer's cross-attention over the target's last-layer KV at the metric's length (131072 rows, Llama-3-8B heads):
+    `GlideAttention.tree_decoding` reads the whole prefix non-causally with 4 / 16 query rows (llama_glide.py:297), `decoding`
+    causally (bottom-right aligned, :265) with the rows accepted last round.  Against a dense fp32 soft-max evaluated by torch
+    on the GPU, relative bound as in test_full_size_verify_attention_vs_oracle; lse to 1e-4.  (These calls have no new-key
+    block: their automatic split count is the one that avoids power-of-two strides between the splits.)"""
+    H, Hkv, L = 32, 8, 131072
+    gen = torch.Generator(device="cpu").manual_seed(77 + sq)
+    q = torch.randn(1, sq, H, 128, generator=gen).to(torch.float16).to(DEV)
+    kc = torch.randn(1, L + 64, Hkv, 128, generator=gen).to(torch.float16).to(DEV)
+    vc = torch.randn(1, L + 64, Hkv, 128, generator=gen).to(torch.float16).to(DEV)
+    cl = torch.tensor([L], dtype=torch.int32, device=DEV)
+    o, lse = ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, causal=causal, return_softmax_lse=True, kv_len_hint=L)
+    g_ = H // Hkv
+    for h0 in range(0, H, 8):
+        qh = q[0, :, h0:h0 + 8].float().permute(1, 0, 2)                                # 8 sq D
+        kh = kc[0, :L, h0 // g_:(h0 + 8) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        vh = vc[0, :L, h0 // g_:(h0 + 8) // g_].float().permute(1, 0, 2).repeat_interleave(g_, 0)
+        s = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(128)
+        if causal:                                                                       # row r sees keys [0, L - sq + r]
+            vis = torch.arange(L, device=DEV)[None, :] <= (L - sq + torch.arange(sq, device=DEV))[:, None]
+            s = s.masked_fill(~vis[None], float("-inf"))
+        ref = torch.matmul(torch.softmax(s, -1), vh).permute(1, 0, 2)
+        assert_close_rel(o[0, :, h0:h0 + 8], ref, ulps=2.0, what=f"cross-attention sq={sq} causal={causal} heads {h0}..")
+        assert (lse[0, h0:h0 + 8] - torch.logsumexp(s, -1)).abs().max().item() <= 1e-4
