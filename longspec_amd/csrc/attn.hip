@@ -1104,14 +1104,30 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         __syncthreads();
     } else {
         f32x4 acc[8][QT];
+#ifndef LS_WS_VALU_ROWSUM
         f32x4 lacc[QT];                            // row 0 of the ones tile: l of query row l15 in the lanes with g4 == 0, element 0
         typename E::V8 ones;                       // A operand of that tile: row 0 (lanes with l15 == 0) = 1 for every key
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = E::from_f32(l15 == 0 ? 1.f : 0.f);
+#else
+        // -DLS_WS_VALU_ROWSUM (round 3, measured, not the default): the row sums on THIS wave's vector pipe -- 20 v_dot2 per
+        // step against (1, 1) instead of the 5 MFMAs of the ones tile (6 % of the SIMD's matrix-pipe time), each lane summing
+        // the 8 keys of its P fragments, the four lanes of a row added once behind the loop.  Correct (233 operator tests) and
+        // SLOWER: 225.1 / 220.8 / 222.1 vs 223.2 / 217.6 / 215.7 us per 128k call, 51.6 vs 50.4 us at 16k (alternating runs on
+        // one box, tools/bench_attn.py --round-like 64) when the compiler places the dot2 (it queues them behind the MFMAs); with
+        // one row tile's four dot2 pinned behind each group of five MFMAs (the form below) 224.2 / 228.1 / 227.1 vs 224.5 /
+        // 217.4 / 220.4 and 51.3 vs 50.1.  Five more MFMAs cost less than twenty vector instructions even in a wave that has
+        // hardly any: the step is not bound by the matrix pipe's issue slots alone.
+        float lsum[QT];
+#endif
         auto run_pass = [&](int mode) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+#ifndef LS_WS_VALU_ROWSUM
                 lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+                lsum[qt] = 0.f;
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -1141,12 +1157,22 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
                         vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
                     }
+#ifndef LS_WS_VALU_ROWSUM
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
+#else
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {       // one row tile's sum pinned behind each group of QT MFMAs
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
+                        if (dt < QT) lsum[dt < QT ? dt : 0] = E::sum8(pf[dt < QT ? dt : 0], lsum[dt < QT ? dt : 0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
                 }
                 WS_TS(1);
                 // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
@@ -1165,8 +1191,13 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         {   // an fp16 P that overflowed (or an inf - inf behind it) leaves a non-finite row sum: redo with the true row maxima
             bool bad = false;
 #pragma unroll
+#ifndef LS_WS_VALU_ROWSUM
             for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lacc[qt][0]) <= 3.0e38f);
             if (__any(bad && g4 == 0) && lane == 0) *redo_flag = 1;
+#else
+            for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lsum[qt]) <= 3.0e38f);
+            if (__any(bad) && lane == 0) *redo_flag = 1;
+#endif
         }
         __syncthreads();
         if (*redo_flag) {
@@ -1183,7 +1214,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         WS_MARK(5);                                // ready to write the partial
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+#ifndef LS_WS_VALU_ROWSUM
             const float lt = __shfl(lacc[qt][0], l15);       // (lanes g4 == 0 hold it)
+#else
+            const float lt = wave_xor_sum_16_32(lsum[qt]);   // the row's four lanes (keys 8 g4 .. 8 g4 + 7 of every block)
+#endif
             const float inv = lt > 0.f ? 1.f / lt : 0.f;
             const int m = row0 + qt * 16 + l15;
             if (m < p.M) {

@@ -61,6 +61,14 @@ struct ElemF16 {
 #endif
     static __device__ __forceinline__ T from_f32(float x) { return (T)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    // c + the sum of the 8 elements (fp32 accumulation): four v_dot2_f32_f16 against (1, 1)
+    static __device__ __forceinline__ float sum8(V8 v, float c) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_fdot2(h2{v[2 * i], v[2 * i + 1]}, one, c, false);
+        return c;
+    }
 };
 struct ElemBF16 {
     using T = __bf16;
@@ -85,6 +93,11 @@ struct ElemBF16 {
 #endif
     static __device__ __forceinline__ T from_f32(float x) { return (T)x; }
     static __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+    static __device__ __forceinline__ float sum8(V8 v, float c) {      // (bf16 -> fp32 is a shift: pairs, then the chain)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c += (float)v[2 * i] + (float)v[2 * i + 1];
+        return c;
+    }
 };
 
 // ---- canonical order of a row's sum of squares (RMSNorm), shared by misc.hip::rmsnorm_rows_kernel and the producers /
