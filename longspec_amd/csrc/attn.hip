@@ -262,9 +262,19 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(base) : "memory", "m0");
 }
 
+// Cache policy of the streamed prefix K/V (every byte is used once per call by one workgroup): -DLS_KV_NT=1 requests it
+// non-temporally (MI355X_MICROARCH "nt-weights"); 0 = default policy.
+#ifndef LS_KV_NT
+#define LS_KV_NT 0
+#endif
+#if LS_KV_NT
+#define LS_KV_POLICY " nt"
+#else
+#define LS_KV_POLICY ""
+#endif
 // one K and one V piece (4 keys each) of the fast DMA path: wave-uniform 64-bit base, 32-bit per-lane offset
 __device__ __forceinline__ void dma16_s(const char* base_uniform, unsigned lane_off, unsigned lds_addr_uniform) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" LS_KV_POLICY
                  :
                  : "v"(lane_off), "s"(base_uniform), "s"(lds_addr_uniform)
                  : "memory", "m0");
@@ -1104,30 +1114,14 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         __syncthreads();
     } else {
         f32x4 acc[8][QT];
-#ifndef LS_WS_VALU_ROWSUM
         f32x4 lacc[QT];                            // row 0 of the ones tile: l of query row l15 in the lanes with g4 == 0, element 0
         typename E::V8 ones;                       // A operand of that tile: row 0 (lanes with l15 == 0) = 1 for every key
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = E::from_f32(l15 == 0 ? 1.f : 0.f);
-#else
-        // -DLS_WS_VALU_ROWSUM (round 3, measured, not the default): the row sums on THIS wave's vector pipe -- 20 v_dot2 per
-        // step against (1, 1) instead of the 5 MFMAs of the ones tile (6 % of the SIMD's matrix-pipe time), each lane summing
-        // the 8 keys of its P fragments, the four lanes of a row added once behind the loop.  Correct (233 operator tests) and
-        // SLOWER: 225.1 / 220.8 / 222.1 vs 223.2 / 217.6 / 215.7 us per 128k call, 51.6 vs 50.4 us at 16k (alternating runs on
-        // one box, tools/bench_attn.py --round-like 64) when the compiler places the dot2 (it queues them behind the MFMAs); with
-        // one row tile's four dot2 pinned behind each group of five MFMAs (the form below) 224.2 / 228.1 / 227.1 vs 224.5 /
-        // 217.4 / 220.4 and 51.3 vs 50.1.  Five more MFMAs cost less than twenty vector instructions even in a wave that has
-        // hardly any: the step is not bound by the matrix pipe's issue slots alone.
-        float lsum[QT];
-#endif
         auto run_pass = [&](int mode) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-#ifndef LS_WS_VALU_ROWSUM
                 lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-                lsum[qt] = 0.f;
-#endif
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -1157,22 +1151,12 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
                         vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
                     }
-#ifndef LS_WS_VALU_ROWSUM
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
-#else
-#pragma unroll
-                    for (int dt = 0; dt < 8; ++dt) {       // one row tile's sum pinned behind each group of QT MFMAs
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
-                        if (dt < QT) lsum[dt < QT ? dt : 0] = E::sum8(pf[dt < QT ? dt : 0], lsum[dt < QT ? dt : 0]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
                 }
                 WS_TS(1);
                 // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
@@ -1191,13 +1175,8 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         {   // an fp16 P that overflowed (or an inf - inf behind it) leaves a non-finite row sum: redo with the true row maxima
             bool bad = false;
 #pragma unroll
-#ifndef LS_WS_VALU_ROWSUM
             for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lacc[qt][0]) <= 3.0e38f);
             if (__any(bad && g4 == 0) && lane == 0) *redo_flag = 1;
-#else
-            for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lsum[qt]) <= 3.0e38f);
-            if (__any(bad) && lane == 0) *redo_flag = 1;
-#endif
         }
         __syncthreads();
         if (*redo_flag) {
@@ -1214,11 +1193,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         WS_MARK(5);                                // ready to write the partial
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-#ifndef LS_WS_VALU_ROWSUM
             const float lt = __shfl(lacc[qt][0], l15);       // (lanes g4 == 0 hold it)
-#else
-            const float lt = wave_xor_sum_16_32(lsum[qt]);   // the row's four lanes (keys 8 g4 .. 8 g4 + 7 of every block)
-#endif
             const float inv = lt > 0.f ? 1.f / lt : 0.f;
             const int m = row0 + qt * 16 + l15;
             if (m < p.M) {
@@ -1268,781 +1243,14 @@ __global__ __launch_bounds__(MAX_THREADS) void attn_partial_ws_kernel(const Attn
     drain_lds_dma();
 }
 
+// The two measured negatives of round 3 (four-wave and ping-pong kernels) live in tools/mb/ and are only compiled into
+// diagnostic variants (tools/build_variant.py w4 -DLS_WITH_W4 / pp -DLS_WITH_PP); the product never dispatches them.
 #ifdef LS_WITH_W4
-// ===================== four-wave prefix path: one wave per SIMD, 512 registers, one mixed instruction stream ==============
-// NOT DISPATCHED: the second measured negative of round 3, kept behind -DLS_WITH_W4 (tools/build_variant.py w4 -DLS_WITH_W4,
-// then LS_ATTN_KERNEL=f; tools/dbg_w4.py checks it against an fp32 reference).  With the compiler's MFMA builtins it is correct
-// and takes 301 us per 128k launch alone against 220 of the warp-specialised kernel (274 vs 199 as a verification call behind a
-// copy kernel); with the accumulators pinned to the AGPR half through asm MFMAs (-DLS_W4_ASM_MFMA: 0 scratch in the steady loop)
-// it is no faster and the results are wrong in a timing-dependent way.  tools/mb/w4_step.hip is the ceiling of the layout: the
-// same step written as ONE asm block with fixed registers runs 1.25-1.28 us on constant operands -- what the warp-specialised
-// kernel already does on zeros (1.26) -- because the lone wave of a SIMD eats every LDS wait itself.  profiles/r3_w4_vs_ws.json.
-// Round 3, second structural attempt.  tools/mb/issue_model.hip: behind one v_mfma_f32_16x16x32 two independent VALU / LDS
-// instructions issue for free (9.9 -> 10.9 ns per MFMA), the third costs 3.5 ns -- in the same wave or in the partner wave
-// alike.  The warp-specialised kernel gives its S wave 2.9 such fillers per MFMA and its O wave 0.5; the ping-pong kernel
-// separated the two kinds of work in time.  Here every SIMD runs ONE wave (the whole 512-entry register file) that owns 5 row
-// tiles end to end and whose step is one block of mutually independent work, software-pipelined two deep:
-//     QK^T of block j+1 (40 MFMAs, -> s_next)   P.V of block j-1 (40 MFMAs, <- pf_old)   soft-max of block j (s_cur -> pf_new)
-// = 80 MFMAs, ~105 VALU and 24 LDS fragment reads (1.6 fillers per MFMA) in the order  MFMA, MFMA, one score's soft-max.  P never
-// leaves registers, row sums are fp32 adds (lse as exact as the general kernel's), K and V are read from LDS by 4 waves instead of
-// 4 + 4 with no P round trip, and the only synchronisation is the ring hand-off: one 4-wave barrier per 32-key step.
-constexpr int W4_QT = 5;
-constexpr int W4_LA = 5;                          // blocks of DMA look-ahead
-constexpr int W4_NK = W4_LA + 1;                  // K(b) is read in step b-1
-constexpr int W4_NV = W4_LA + 3;                  // V(b) is read in step b+1
-constexpr int W4_RING_B = (W4_NK + W4_NV) * WS_BLK_B;
-constexpr int W4_LDS = W4_RING_B + 64 + 4 * W4_QT * 64 * 4;     // + the rows' soft-max references, parked for the epilogue
-constexpr int W4_NEW_CAP = W4_RING_B / (2 * ROWB);
-
-template <typename E>
-__device__ __forceinline__ void prefix_path_w4(const AttnK& p, char* smem, int split, int wave) {
-    constexpr int QT = W4_QT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int bi = blockIdx.z, kvh = blockIdx.y % p.Hkv, chunk = blockIdx.y / p.Hkv;
-    const int L = p.cache_seqlens[bi];
-    const float c = p.scale * LOG2E;
-    const int row0 = chunk * p.rows_per_chunk + wave * QT * 16;
-    // (nothing that is only needed in the prologue or the epilogue is kept in a register across the step loop: the vector half of
-    // the file holds two score sets, two weight sets and the fragments in flight, and a spilled lane constant costs more than
-    // its reload -- the compiler drains the DMA look-ahead with s_waitcnt vmcnt(0) in front of every scratch read)
-    typedef __attribute__((address_space(3))) char lds_char;
-    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;
-    const LaneTbl tb = make_lane_tbl(l15, g4);
-    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const long kc_row = p.kc_ss * 2;
-    int* redo_flag = reinterpret_cast<int*>(smem + W4_RING_B);
-    float* mref_lds = reinterpret_cast<float*>(smem + W4_RING_B + 64) + (wave * QT) * 64 + lane;      // [wave][qt][lane]
-
-    const int nb_all = (L + 31) / 32;
-    const int bps = (nb_all + p.n_splits - 1) / p.n_splits;
-    const int b_begin = split * bps;
-    const int n = max(0, min(b_begin + bps, nb_all) - b_begin);
-    const int last_key = L - 1;
-    const bool ragged = (b_begin + n) * 32 > L;
-
-    // two K pieces and two V pieces (4 keys each) per wave and block: pieces 2*wave, 2*wave + 1
-    const int kq_ = lane >> 4, pos_ = lane & 15;
-    unsigned koff_[2], voff_[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pc = 2 * wave + i;
-        koff_[i] = (unsigned)(kq_ * kc_row) + ((pos_ ^ (((pc & 3) << 2) | kq_)) << 4);
-        voff_[i] = (unsigned)(kq_ * kc_row) + ((pos_ ^ ((((pc & 1) << 2) | kq_) << 1)) << 4);
-    }
-    auto k_addr = [&](int b) __attribute__((always_inline)) -> unsigned { return smem_a + (b % W4_NK) * WS_BLK_B; };
-    auto v_addr = [&](int b) __attribute__((always_inline)) -> unsigned { return smem_a + (W4_NK + b % W4_NV) * WS_BLK_B; };
-    auto dma = [&](int b) __attribute__((always_inline)) {
-        const int bg = b_begin + b;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pc = 2 * wave + i;
-            if (bg * 32 + 32 <= L) {
-                const long row = ((long)bg * 32 + pc * 4) * kc_row;
-                dma16_s(kc_base + row, koff_[i], k_addr(b) + pc * 1024);
-                dma16_s(vc_base + row, voff_[i], v_addr(b) + pc * 1024);
-            } else {
-                const int key = pc * 4 + kq_;
-                const long ka = min(bg * 32 + key, last_key);               // tail rows: re-read the last valid key (masked)
-                dma16(kc_base + ka * kc_row + ((pos_ ^ (key & 15)) << 4), smem + (b % W4_NK) * WS_BLK_B + pc * 1024);
-                dma16(vc_base + ka * kc_row + ((pos_ ^ ((key & 7) << 1)) << 4), smem + (W4_NK + b % W4_NV) * WS_BLK_B + pc * 1024);
-            }
-        }
-    };
-    auto wait_block = [&](int need, int issued) __attribute__((always_inline)) {              // blocks 0 .. issued-1 requested (4 pieces each)
-        if (need >= issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-        wait_vmcnt(4 * (issued - 1 - need));
-    };
-
-    typename E::V8 qf[QT][4];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
-        const int rrow = m < p.M ? m % p.sq : 0;
-        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow * p.q_ss +
-                                  (long)head * p.q_sh + g4 * 8;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            typename E::V8 v = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
-            if (m >= p.M)                                      // padding rows multiply zeros (see prefix_path_ws)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = E::from_f32(0.f);
-            // Q^T lives in the ACCUMULATOR half of the register file for the whole kernel (its only readers are the QK^T MFMAs'
-            // B operands): the value has to be BORN there -- a vector-half value with "a" uses is copied into a scratch quad of
-            // the accumulator half in front of every MFMA (and spilled in between)
-            asm volatile("" : "+a"(v));               // (an empty statement whose operand is pinned to the accumulator half)
-            qf[qt][k4] = v;
-        }
-    }
-
-    f32x4 acc[8][QT];
-    float lsum[QT], mref[QT], negmc[QT];
-    float pmax = 0.f;
-    f32x4 sA[2][QT], sB[2][QT];               // scores of two consecutive blocks
-    typename E::V8 pA[QT], pB[QT];            // weights of two consecutive blocks
-    typename E::V8 kf[4][2];
-    union VF {
-        struct { s16x4 a, b; } s;
-        typename E::V8 v;
-    } vf[8];
-
-    // fragment loaders: ONE k-step of K (two 16-key tiles) / ONE 16-column tile of V^T at a time -- the step body requests a
-    // fragment a few groups before its first MFMA and lets it die behind its last one (rolling: 24 registers of fragments live
-    // instead of 64; with all of them fetched up front the wave needs 14-28 registers more than the vector half has)
-    auto k_frag = [&](unsigned kbase, int k4) __attribute__((always_inline)) {
-        int kx = tb.kx;
-        asm volatile("" : "+v"(kx));           // see qk_block
-        const unsigned kb = kbase + tb.kb;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
-    };
-    auto v_frag = [&](unsigned vbase, int dt) __attribute__((always_inline)) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        int vx = tb.vx;
-        asm volatile("" : "+v"(vx));           // see qk_block
-        const unsigned va = vbase + tb.vb + ((dt ^ vx) << 5);
-        vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
-        vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
-    };
-    auto k_load = [&](unsigned kbase) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) k_frag(kbase, k4);
-    };
-    auto v_load = [&](unsigned vbase) __attribute__((always_inline)) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) v_frag(vbase, dt);
-    };
-    auto mask_tail = [&](f32x4 (&s)[2][QT], int b) __attribute__((always_inline)) {
-        const int ka0 = (b_begin + b) * 32;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (ka0 + kt * 16 + g4 * 4 + e >= L) s[kt][qt][e] = -INFINITY;
-    };
-    auto row_max = [&](const f32x4 (&s)[2][QT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float v = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                                  fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-            mref[qt] = fmaxf(mref[qt], wave_xor_max_16_32(v));
-        }
-    };
-    // One step's work, as ONE unrolled sequence of 40 groups: { QK^T MFMA g, P.V MFMA g, the soft-max of score g }.
-    //   QK^T MFMA g:  k4 = g / 10, (qt, kt) = g % 10   -> an accumulator is revisited every 10th group
-    //   P.V  MFMA g:  dt = g / 5, qt = g % 5           -> every accumulator once
-    //   score g:      qt = g / 8, element g % 8
-    auto step_body = [&](auto has_qk_, auto has_pv_, unsigned kbase, unsigned vbase, f32x4 (&s_in)[2][QT], f32x4 (&s_out)[2][QT],
-                         typename E::V8 (&p_in)[QT], typename E::V8 (&p_out)[QT]) __attribute__((always_inline)) {
-        constexpr bool HAS_QK = decltype(has_qk_)::value, HAS_PV = decltype(has_pv_)::value;
-        if (HAS_QK) k_frag(kbase, 0);
-        if (HAS_PV) { v_frag(vbase, 0); v_frag(vbase, 1); }
-        if (HAS_QK) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) s_out[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        float ps[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) ps[qt] = 0.f;
-        float pe_prev = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8 * QT; ++g) {
-            if (HAS_QK && g % (2 * QT) == 0 && g / (2 * QT) + 1 < 4) k_frag(kbase, g / (2 * QT) + 1);     // one k-step ahead
-            if (HAS_PV && g % QT == 0 && g / QT + 2 < 8) v_frag(vbase, g / QT + 2);                       // two d tiles ahead
-            if (HAS_QK) {
-                const int k4 = g / (2 * QT), r = g % (2 * QT), qt = r >> 1, kt = r & 1;
-                E::mfma_b_a(kf[k4][kt], qf[qt][k4], s_out[kt][qt]);
-            }
-            if (HAS_PV) {
-                const int dt = g / QT, qt = g % QT;
-                E::mfma_acc_a(vf[dt].v, p_in[qt], acc[dt][qt]);
-            }
-            {
-                const int qt = g >> 3, e8 = g & 7, kt = e8 >> 2, e = e8 & 3;
-                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s_in[kt][qt][e], c, negmc[qt]));
-                ps[qt] += pe;
-                if (e8 & 1) {
-                    p_out[qt][e8 - 1] = E::from_f32(pe_prev);
-                    p_out[qt][e8] = E::from_f32(pe);
-                }
-                pe_prev = pe;
-            }
-#ifndef LS_W4_FREE_SCHED
-            __builtin_amdgcn_sched_barrier(0);     // pin the mix: nothing moves across a group boundary
+#include "../../tools/mb/attn_w4_kernel.inc"
 #endif
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            lsum[qt] += ps[qt];
-            pmax = fmaxf(pmax, ps[qt]);
-        }
-    };
-    // step j: [DMA j+1+LA] [fragments: K(j+1), V(j-1)] [QK^T(j+1) -> s_out | P.V(j-1) <- p_in | soft-max(s_in) -> p_out] [ring hand-off]
-    auto step = [&](int j, int& issued, auto has_qk_, auto has_pv_, f32x4 (&s_in)[2][QT], f32x4 (&s_out)[2][QT],
-                    typename E::V8 (&p_in)[QT], typename E::V8 (&p_out)[QT]) __attribute__((always_inline)) {
-        if (j + 1 + W4_LA < n) { dma(j + 1 + W4_LA); ++issued; }
-        step_body(has_qk_, has_pv_, k_addr(j + 1), v_addr(j - 1), s_in, s_out, p_in, p_out);
-        if (decltype(has_qk_)::value && ragged && j + 2 == n) {   // block j+1 is the split's last and crosses the end of the cache
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // (its MFMAs are asm statements: let them retire before compiler code reads s_out)
-            mask_tail(s_out, j + 1);
-        }
-        wait_block(j + 2, issued);                 // K(j+2) is multiplied in step j+1
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    auto qk_first = [&](unsigned kbase) __attribute__((always_inline)) {          // sA = S^T of one block, outside the pipeline (prologue, maxima pass)
-        k_load(kbase);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sA[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) E::mfma_b_a(kf[k4][kt], qf[qt][k4], sA[kt][qt]);
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // (the readers below are compiler code: let the last MFMAs retire)
-    };
-
-    auto max_pass = [&]() __attribute__((always_inline)) {                        // QK^T only, for the true row maxima (after a numerator near the fp16 range)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) mref[qt] = -INFINITY;
-        int issued = 0;
-        for (; issued < min(n, 2); ++issued) dma(issued);
-        for (int b = 0; b < n; ++b) {
-            wait_block(b, issued);
-            __builtin_amdgcn_s_barrier();
-            qk_first(k_addr(b));
-            if (ragged && b == n - 1) mask_tail(sA, b);
-            row_max(sA);
-            __builtin_amdgcn_s_barrier();
-            if (issued < n) dma(issued++);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    auto main_pass = [&](bool have_ref) __attribute__((always_inline)) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            lsum[qt] = 0.f;
-            if (!have_ref) mref[qt] = -INFINITY;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                // pinned where it stands (an empty statement that "rewrites" the accumulator in the accumulator half): the
-                // compiler otherwise sinks the zeroing to just in front of the first asm MFMA that reads it (n = 1: measured
-                // wrong), closer than a write of the accumulator half may be to an MFMA that reads it
-                acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                asm volatile("" : "+a"(acc[dt][qt]));
-            }
-        }
-        asm volatile("s_nop 7" ::: "memory");
-        pmax = 0.f;
-        int issued = 0;
-        for (; issued < min(n, W4_LA + 1); ++issued) dma(issued);
-        wait_block(1, issued);                     // blocks 0 and 1
-        __builtin_amdgcn_s_barrier();
-        if (n == 0) return;
-        qk_first(k_addr(0));
-        if (ragged && n == 1) mask_tail(sA, 0);
-        if (!have_ref) row_max(sA);                // the reference: the row's maximum over the split's first 32 keys
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const bool pad = row0 + qt * 16 + l15 >= p.M;
-            if (pad) mref[qt] = INFINITY;          // padding rows: weights exactly zero
-            negmc[qt] = pad ? -INFINITY : -(mref[qt] == -INFINITY ? 0.f : mref[qt]) * c;
-            mref_lds[qt * 64] = mref[qt];          // (read back by the epilogue; not held across the loop)
-        }
-        // step 0 (no P.V yet), pairs of steps with the two score / weight register sets swapping roles, the last one or two
-        // QK^T steps, the last step (no QK^T), then the P.V of the last block.  Invariant at `tail`: scores of block j in sB,
-        // weights of block j-1 in pA.
-        auto pv_only = [&](typename E::V8 (&pw)[QT]) __attribute__((always_inline)) {
-            v_load(v_addr(n - 1));
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) E::mfma_acc_a(vf[dt].v, pw[qt], acc[dt][qt]);
-        };
-        if (n == 1) {
-            step(0, issued, F_{}, F_{}, sA, sB, pB, pA);
-            pv_only(pA);
-            return;
-        }
-        step(0, issued, T_{}, F_{}, sA, sB, pB, pA);
-        int j = 1;
-#pragma unroll 1
-        for (; j + 2 < n - 1; j += 2) {            // both steps multiply a K block that is not the split's last
-            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
-            step(j + 1, issued, T_{}, T_{}, sA, sB, pB, pA);
-        }
-        const int rest = n - 1 - j;                // QK^T steps left: 0 (n = 2), 1 or 2
-        if (rest == 2) {
-            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
-            step(j + 1, issued, T_{}, T_{}, sA, sB, pB, pA);
-            step(n - 1, issued, F_{}, T_{}, sB, sA, pA, pB);
-            pv_only(pB);
-        } else if (rest == 1) {
-            step(j, issued, T_{}, T_{}, sB, sA, pA, pB);
-            step(n - 1, issued, F_{}, T_{}, sA, sB, pB, pA);
-            pv_only(pA);
-        } else {
-            step(n - 1, issued, F_{}, T_{}, sB, sA, pA, pB);
-            pv_only(pB);
-        }
-    };
-
-#pragma unroll 1
-    for (int attempt = 0; attempt < 2; ++attempt) {           // (one copy of the pass in the binary)
-        main_pass(attempt == 1);
-        if (attempt == 1) break;
-        if (tid == 0) *redo_flag = 0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;      // fp16 tops out at 65504: two octaves below it
-        __syncthreads();
-        if (!*redo_flag) break;
-        __syncthreads();
-        max_pass();
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last P.V MFMAs are asm statements: retire before the epilogue reads acc
-
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const float lt = wave_xor_sum_16_32(lsum[qt]);
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        const int m = row0 + qt * 16 + l15;
-        if (m < p.M) {
-            const float lse = lt > 0.f ? mref_lds[qt * 64] * p.scale + __logf(lt) : -INFINITY;
-            const int head = kvh * p.g + m / p.sq;
-            const int rrow = m % p.sq;
-            float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow) * p.H + head) * D + g4 * 4;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
-            if (g4 == 0) p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow] = lse;
-        }
-    }
-}
-
-template <typename E>
-__global__ __launch_bounds__(256, 1) void attn_partial_w4_kernel(const AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (p.has_new && blockIdx.x == 0) {            // new-key block: 4 workers x 5 row tiles (one at a time)
-        KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
-        if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 5, LS_NEW_TARGET>(pk, smem);
-        else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 5, LS_NEW_DRAFT>(pk, smem);
-        else new_block_path<E, 5, LS_NEW_FLASH>(pk, smem);
-    } else {
-        prefix_path_w4<E>(p, smem, (int)blockIdx.x - p.has_new, w);
-    }
-    drain_lds_dma();
-}
-#endif  // LS_WITH_W4
-
 #ifdef LS_WITH_PP
-// ===================== ping-pong prefix path (verification-sized row blocks, 17..24 row tiles) =====================
-// NOT DISPATCHED: a measured negative of round 3, kept behind -DLS_WITH_PP (tools/build_variant.py pp -DLS_WITH_PP, then
-// LS_ATTN_KERNEL=pp) with its profile hooks so that the measurement can be repeated: 197 vs 164 us per 128k launch inside the
-// decode round, 111 vs 89 us at the QwQ head layout against the general kernel (profiles/r3_pp_vs_ws.json).
-// The idea.  The warp-specialised split above makes ONE wave (S) the critical path of both pipes: its 40 QK^T MFMAs and all
-// of the soft-max VALU work (40 fma, 40 quarter-rate v_exp_f32, 20 conversions per 32-key step) have to interleave inside
-// one in-order instruction stream, and they mostly do not (1.24 us per step against 0.6 us of matrix time).
-// Here every wave owns 2 or 3 row tiles END TO END -- S^T = K.Q^T, p = 2^((s-m)c), O^T += V^T.P^T, P never leaves its
-// registers, no LDS hand-off -- and its step is two PURE segments: M (P.V of block j-1, then QK^T of block j: 32 or 48
-// MFMAs, LDS fragment reads) and V (the soft-max numerators of block j: VALU only, plus the wave's two DMA pieces).  The
-// two waves of a SIMD (w and w+4) run the same segment sequence HALF A STEP APART, held there by two workgroup barriers
-// per step: while wave w is in M, wave w+4 is in V, so the matrix pipe and the vector ALU of the SIMD are both fed by
-// construction instead of by instruction scheduling.  19 row tiles are dealt 3,3,3,2 | 2,2,2,2 (5,5,5,4 per SIMD: no sixth
-// padding tile), 24 (GQA-5 x 74 rows) 3 everywhere.
-//   phase        P(2j)           P(2j+1)          P(2j+2)
-//   waves 0-3    V(j)            M(j+1)           V(j+1)            V(j): s(j) -> p(j)      M(j+1): P.V(j), QK^T(j+1)
-//   waves 4-7    M(j)            V(j)             M(j+1)
-// The reference m of a row is its maximum over the split's first 32 keys and stays fixed (no rescaling: lse = m*scale +
-// ln l holds for any m); a block sum within two octaves of the fp16 range redoes the split with the true row maxima.
-// K/V blocks (32 keys, 8 KB each) stream through two rings by LDS DMA, PP_D blocks ahead: block x is issued in V(x - D),
-// K(x) is read in M(x) (both halves: until barrier 2x), V(x) in M(x+1) (until barrier 2x+2) -- hence D+1 and D+2 slots.
-template <int N> using IC = std::integral_constant<int, N>;
-#ifndef LS_PP_D
-#define LS_PP_D 6
+#include "../../tools/mb/attn_pp_kernel.inc"
 #endif
-constexpr int PP_D = LS_PP_D;
-constexpr int PP_NK = PP_D + 1;
-constexpr int PP_NV = PP_D + 2;
-constexpr int PP_RING_B = (PP_NK + PP_NV) * WS_BLK_B;      // 120 KB
-constexpr int PP_LDS = PP_RING_B + 64;
-constexpr int PP_NEW_CAP = PP_RING_B / (2 * ROWB);         // keys the new-block workgroup can hold in the same LDS
-
-template <typename E, int QT, int ROLE>
-__device__ __forceinline__ void prefix_path_pp(const AttnK& p, char* smem, int split, int tile0) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int bi = blockIdx.z, kvh = blockIdx.y % p.Hkv, chunk = blockIdx.y / p.Hkv;
-    const int L = p.cache_seqlens[bi];
-    const float c = p.scale * LOG2E;
-    const int row0 = chunk * p.rows_per_chunk + tile0 * 16;
-    int rrow[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        rrow[qt] = m < p.M ? m % p.sq : 0;        // padding rows: computed, never stored
-    }
-    typedef __attribute__((address_space(3))) char lds_char;
-    const unsigned smem_a = (unsigned)(uintptr_t)(lds_char*)smem;
-    const LaneTbl tb = make_lane_tbl(l15, g4);
-    const char* kc_base = reinterpret_cast<const char*>(p.k_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const char* vc_base = reinterpret_cast<const char*>(p.v_cache) + ((long)bi * p.kc_sb + (long)kvh * p.kc_sh) * 2;
-    const long kc_row = p.kc_ss * 2;
-    int* redo_flag = reinterpret_cast<int*>(smem + PP_RING_B);
-
-    // the split's key range in 32-key blocks (splits are cut at 64-key tile boundaries, as in the other paths)
-    const int t1 = (L + 63) / 64;
-    const int tps = (t1 + p.n_splits - 1) / p.n_splits;
-    const int b_begin = split * tps * 2;
-    const int n = max(0, min(b_begin + tps * 2, (L + 31) / 32) - b_begin);
-    const int last_key = L - 1;
-    const bool ragged = (b_begin + n) * 32 > L;                  // the split's last block crosses the end of the cache
-
-    // one K piece and one V piece (4 keys each) per wave and block; see prefix_path_ws for the addressing
-    const int kq_ = lane >> 4, pos_ = lane & 15;
-    const unsigned koff_ = (unsigned)(kq_ * kc_row) + ((pos_ ^ (((wave & 3) << 2) | kq_)) << 4);
-    const unsigned voff_ = (unsigned)(kq_ * kc_row) + ((pos_ ^ ((((wave & 1) << 2) | kq_) << 1)) << 4);
-    auto dma = [&](int b) {
-        const int bg = b_begin + b;
-        if (bg * 32 + 32 <= L) {
-            const long row = ((long)bg * 32 + wave * 4) * kc_row;
-            dma16_s(kc_base + row, koff_, smem_a + (b % PP_NK) * WS_BLK_B + wave * 1024);
-            dma16_s(vc_base + row, voff_, smem_a + (PP_NK + b % PP_NV) * WS_BLK_B + wave * 1024);
-        } else {
-            const int key = wave * 4 + kq_;
-            const long ka = min(bg * 32 + key, last_key);                   // tail rows: re-read the last valid key (masked)
-            dma16(kc_base + ka * kc_row + ((pos_ ^ (key & 15)) << 4), smem + (b % PP_NK) * WS_BLK_B + wave * 1024);
-            dma16(vc_base + ka * kc_row + ((pos_ ^ ((key & 7) << 1)) << 4), smem + (PP_NK + b % PP_NV) * WS_BLK_B + wave * 1024);
-        }
-    };
-    auto k_addr = [&](int b) -> unsigned { return smem_a + (b % PP_NK) * WS_BLK_B; };
-    auto v_addr = [&](int b) -> unsigned { return smem_a + (PP_NK + b % PP_NV) * WS_BLK_B; };
-    // blocks 0 .. issued-1 have been requested by this wave; return once block `need` (and everything older) has landed
-    auto wait_block = [&](int need, int issued) {
-        if (need >= issued) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-        wait_vmcnt(2 * (issued - 1 - need));
-    };
-    auto phase_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);         // the segments stay pure: nothing is scheduled across a phase boundary
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // Q^T fragments
-    typename E::V8 qf[QT][4];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int m = row0 + qt * 16 + l15;
-        const int head = kvh * p.g + (m < p.M ? m / p.sq : 0);
-        const typename E::T* qp = reinterpret_cast<const typename E::T*>(p.q) + (long)bi * p.q_sb + (long)rrow[qt] * p.q_ss +
-                                  (long)head * p.q_sh + g4 * 8;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) qf[qt][k4] = *reinterpret_cast<const typename E::V8*>(qp + k4 * 32);
-    }
-
-    f32x4 acc[8][QT];
-    float lsum[QT], mref[QT], negmc[QT];
-    float pmax = 0.f;
-    f32x4 s[2][QT];
-    typename E::V8 pf[QT];
-#ifdef LS_PP_PROF
-    // wall-clock profile (s_memrealtime, 100 MHz) of the step's segments, summed over all steps of workgroup (split 1, kv head 0):
-    // V body | vmcnt wait (role 0) | barrier behind V | M body | vmcnt wait (role 1) | barrier behind M -- tools/pp_prof.py
-    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long pt = 0;
-#define PP_T0() do { __builtin_amdgcn_sched_barrier(0); pt = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PP_TS(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); prof[i] += n_ - pt; pt = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PP_T0()
-#define PP_TS(i)
-#endif
-
-    // The fragment reads of a segment are issued as one batch ahead of its MFMAs (LDS returns in order: the P.V MFMAs wait
-    // for the V^T fragments only, the QK^T ones for the K fragments behind them) -- one exposed LDS latency per segment.
-    typename E::V8 kf[4][2];
-    union VF {
-        struct { s16x4 a, b; } s;
-        typename E::V8 v;
-    } vf[8];
-    constexpr int KPRE = QT >= 3 ? 0 : 4;      // K k-steps fetched ahead of the barrier as well (block j+1 lands a phase early)
-    auto k_load = [&](unsigned kbase, auto lo_, auto hi_) {
-        int kx = tb.kx;
-        asm volatile("" : "+v"(kx));           // see qk_block
-        const unsigned kb = kbase + tb.kb;
-#pragma unroll
-        for (int k4 = decltype(lo_)::value; k4 < decltype(hi_)::value; ++k4)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
-    };
-    auto qk_mma = [&]() {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[k4][kt], qf[qt][k4], s[kt][qt]);
-    };
-    auto qk = [&](int b) {                                     // s = S^T of block b
-        k_load(k_addr(b), IC<0>{}, IC<4>{});
-        qk_mma();
-    };
-    // 3-tile waves are within a dozen registers of the 256 they have: they fetch half of the V^T fragments ahead of the
-    // barrier and the K fragments only once the first half of the P.V MFMAs has released its operands
-    constexpr int VPRE = QT >= 3 ? 4 : 8;
-    auto v_load = [&](unsigned vbase, auto lo_, auto hi_) {
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        int vx = tb.vx;
-        asm volatile("" : "+v"(vx));           // see qk_block
-        const unsigned vb = vbase + tb.vb;
-#pragma unroll
-        for (int dt = decltype(lo_)::value; dt < decltype(hi_)::value; ++dt) {
-            const unsigned va = vb + ((dt ^ vx) << 5);
-            vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
-            vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
-        }
-    };
-    auto pv_mma = [&](auto lo_, auto hi_) {                    // acc += V^T . P^T, d tiles [lo, hi)
-#pragma unroll
-        for (int dt = decltype(lo_)::value; dt < decltype(hi_)::value; ++dt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
-    };
-    auto mask_tail = [&](int b) {
-        const int ka0 = (b_begin + b) * 32;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (ka0 + kt * 16 + g4 * 4 + e >= L) s[kt][qt][e] = -INFINITY;
-    };
-    auto row_max = [&]() {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const float v = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                                  fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-            mref[qt] = fmaxf(mref[qt], wave_xor_max_16_32(v));
-        }
-    };
-    auto softmax = [&]() {                                     // V segment: p = 2^(s*c - m*c), fp32 row sums, P -> dtype
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#ifdef LS_PP_ABL_NOEXP
-                    const float pe = __builtin_fmaf(s[kt][qt][e], c, negmc[qt]);       // (ablation: wrong results)
-#else
-                    const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, negmc[qt]));
-#endif
-                    ps += pe;
-                    pf[qt][kt * 4 + e] = E::from_f32(pe);
-                }
-            lsum[qt] += ps;
-            pmax = fmaxf(pmax, ps);        // sum of 8 numerators: a conservative stand-in for their max
-        }
-    };
-    // QK-only pass for the true row maxima (only after a numerator came close to the fp16 range): plain double buffering
-    auto max_pass = [&]() {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) mref[qt] = -INFINITY;
-        int issued = 0;
-        for (; issued < min(n, 2); ++issued) dma(issued);
-        for (int b = 0; b < n; ++b) {
-            wait_block(b, issued);
-            phase_barrier();
-            qk(b);
-            if (ragged && b == n - 1) mask_tail(b);
-            row_max();
-            phase_barrier();                       // every wave is done with K slot b % NK
-            if (issued < n) dma(issued++);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        phase_barrier();
-    };
-
-    auto main_pass = [&](bool have_ref) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            lsum[qt] = 0.f;
-            if (!have_ref) mref[qt] = -INFINITY;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        pmax = 0.f;
-        int issued = 0;
-        for (; issued < min(n, PP_D); ++issued) dma(issued);
-        wait_block(1, issued);                     // blocks 0 and 1: V(0) already fetches K fragments of block 1
-        phase_barrier();
-        if (n > 0) {
-            qk(0);
-            if (ragged && n == 1) mask_tail(0);
-            if (!have_ref) row_max();
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) negmc[qt] = -(mref[qt] == -INFINITY ? 0.f : mref[qt]) * c;
-        if (ROLE == 1) phase_barrier();            // barrier 0: half a step behind the partner wave of the SIMD
-        // Steady steps (j + D < n - 1): the block requested lies inside the cache (wave-uniform base + one offset register),
-        // the look-ahead is full (immediate wait counts), block j+1 is not the ragged one.  The generic form runs the rest.
-        // ring positions (LDS byte addresses), advanced by one slot per step instead of a modulo per access
-        unsigned k_iss = k_addr(issued), v_iss = v_addr(issued);       // block j + D: the next one to request
-        unsigned k_nxt = k_addr(1), v_cur = v_addr(0);                 // K of block j + 1, V of block j
-        const unsigned k_end = smem_a + PP_NK * WS_BLK_B, v_end = k_end + PP_NV * WS_BLK_B;
-        auto adv_k = [&](unsigned& a) { a += WS_BLK_B; a = a == k_end ? smem_a : a; };
-        auto adv_v = [&](unsigned& a) { a += WS_BLK_B; a = a == v_end ? k_end : a; };
-        auto step = [&](int j, auto steady_) {
-            constexpr bool STEADY = decltype(steady_)::value;
-            PP_T0();
-            // ---- V(j): the wave's DMA pieces, the V^T fragments of the coming P.V (block j landed a step ago), soft-max
-            if constexpr (STEADY) {
-                const long row = ((long)(b_begin + j + PP_D) * 32 + wave * 4) * kc_row;
-                dma16_s(kc_base + row, koff_, k_iss + wave * 1024);
-                dma16_s(vc_base + row, voff_, v_iss + wave * 1024);
-                ++issued;
-            } else if (j + PP_D < n) {
-                dma(j + PP_D);
-                ++issued;
-            }
-            adv_k(k_iss);
-            adv_v(v_iss);
-            const bool more = STEADY || j + 1 < n;
-            v_load(v_cur, IC<0>{}, IC<VPRE>{});
-            if (more) k_load(k_nxt, IC<0>{}, IC<KPRE>{});
-            softmax();
-            PP_TS(0);
-            if (ROLE == 1) {                                   // every piece of block j+2 has landed behind barrier 2j+1
-                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PP_D - 2)) : "memory");
-                else wait_block(j + 2, issued);
-            }
-            PP_TS(1);
-            phase_barrier();                                   // ROLE 0: barrier 2j, ROLE 1: barrier 2j+1
-            PP_TS(2);
-            // ---- M(j+1): the rest of the fragments, P.V(j), QK^T(j+1)
-            if (VPRE < 8) v_load(v_cur, IC<VPRE>{}, IC<8>{});
-            adv_v(v_cur);
-#ifndef LS_PP_NOPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-            pv_mma(IC<0>{}, IC<4>{});
-            if (KPRE < 4 && more) k_load(k_nxt, IC<KPRE>{}, IC<4>{});
-            adv_k(k_nxt);
-            pv_mma(IC<4>{}, IC<8>{});
-            if (more) qk_mma();
-#ifndef LS_PP_NOPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            if constexpr (!STEADY)
-                if (ragged && j + 2 == n) mask_tail(j + 1);
-            PP_TS(3);
-            if (ROLE == 0) {
-                if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PP_D - 2)) : "memory");
-                else wait_block(j + 2, issued);
-                PP_TS(4);
-                phase_barrier();                               // barrier 2j+1
-            } else if (more) {
-                phase_barrier();                               // barrier 2j+2
-            }
-            PP_TS(5);
-        };
-        const int n_steady = max(0, n - 1 - PP_D);
-#pragma unroll 1
-        for (int j = 0; j < n_steady; ++j) step(j, std::true_type{});
-#pragma unroll 1
-        for (int j = n_steady; j < n; ++j) step(j, std::false_type{});
-    };
-
-    main_pass(false);
-    if (tid == 0) *redo_flag = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (__any(pmax > 16384.f) && lane == 0) *redo_flag = 1;      // fp16 tops out at 65504: two octaves below it
-    __syncthreads();
-    if (*redo_flag) {
-        __syncthreads();
-        max_pass();
-        main_pass(true);
-    }
-
-#ifdef LS_PP_PROF
-    if (!p.has_new && split == 1 && kvh == 0 && bi == 0 && lane < 8)
-        reinterpret_cast<unsigned long long*>(p.new_o)[wave * 8 + lane] =
-            lane < 6 ? (prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) + prof[3] * (lane == 3) +
-                        prof[4] * (lane == 4) + prof[5] * (lane == 5))
-                     : (lane == 6 ? (unsigned long long)n : (unsigned long long)QT);
-#endif
-    // ---- write the (normalised) partial
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const float lt = wave_xor_sum_16_32(lsum[qt]);
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        const float lse = lt > 0.f ? mref[qt] * p.scale + __logf(lt) : -INFINITY;
-        const int m = row0 + qt * 16 + l15;
-        if (m < p.M) {
-            const int head = kvh * p.g + m / p.sq;
-            float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
-            if (g4 == 0) p.parts_lse[(((long)split * p.b + bi) * p.H + head) * p.sq + rrow[qt]] = lse;
-        }
-    }
-}
-
-template <typename E>
-__global__ __launch_bounds__(MAX_THREADS) void attn_partial_pp_kernel(const AttnK p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.has_new && blockIdx.x == 0) {            // the new-key block keeps the general path's row split
-        KernArgAttnK* pk = (KernArgAttnK*)__builtin_amdgcn_kernarg_segment_ptr();
-        const int rb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (rb < p.rbA) {
-            if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 3, LS_NEW_TARGET>(pk, smem);
-            else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 3, LS_NEW_DRAFT>(pk, smem);
-            else new_block_path<E, 3, LS_NEW_FLASH>(pk, smem);
-        } else {
-            if (p.new_mode == LS_NEW_TARGET) new_block_path<E, 2, LS_NEW_TARGET>(pk, smem);
-            else if (p.new_mode == LS_NEW_DRAFT) new_block_path<E, 2, LS_NEW_DRAFT>(pk, smem);
-            else new_block_path<E, 2, LS_NEW_FLASH>(pk, smem);
-        }
-    } else {
-        // wave w < 4 and wave w + 4 share a SIMD (round-robin placement) and run half a step apart.  The first `pp_extra`
-        // waves carry 3 row tiles, the others 2:  tiles = 16 + pp_extra.
-        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int e = p.pp_extra;
-        const int split = (int)blockIdx.x - p.has_new;
-        const int tile0 = w < e ? 3 * w : 3 * e + 2 * (w - e);
-        if (w < 4) {
-            if (w < e) prefix_path_pp<E, 3, 0>(p, smem, split, tile0);
-            else prefix_path_pp<E, 2, 0>(p, smem, split, tile0);
-        } else {
-            if (w < e) prefix_path_pp<E, 3, 1>(p, smem, split, tile0);
-            else prefix_path_pp<E, 2, 1>(p, smem, split, tile0);
-        }
-    }
-    drain_lds_dma();
-}
-
-#endif  // LS_WITH_PP
 
 // Row blocks 0..rbA-1 carry QTA tiles, the rest QTB: both instantiations execute the same barrier
 // sequence (identical tile loop), so a workgroup may mix them wave by wave.

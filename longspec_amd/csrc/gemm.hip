@@ -83,11 +83,34 @@ enum { EPI_NONE = 0, EPI_SILU_MUL = 1, EPI_QKV_ROPE = 2 };
 
 // agent-coherent accesses (sc1: write-through / cache-bypassing), so that partials written by a workgroup
 // on one XCD are read correctly by the reducing workgroup on another without an L2 write-back + invalidate
-__device__ __forceinline__ void st_coherent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// 16 bytes per lane (one accumulator quad): scalar sc1 stores are one fabric write EACH -- a dword costs ~6x the time per
+// byte of a dwordx4 (MI355X_MICROARCH, visibility table) -- so a partial tile travels as `buffer_store_dwordx4 ... sc1` of
+// the lane's f32x4, 1 KB contiguous per wave-instruction.  aux 16 = sc1 on gfx950.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const float* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ float ld_coherent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void st_coherent4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ f32x4 ld_coherent4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+// The weight stream: every byte is read ONCE per launch by ONE workgroup, so it is requested non-temporally
+// (`global_load_dwordx4 ... nt`: no allocation priority in L2 / MALL -- the x rows, the partials and the next kernel's
+// operands keep the cache).  MI355X_MICROARCH "nt-weights": issue -> landed -18 %, 5-10 % per decode layer.
+// -DLS_GEMM_NT=0 builds the default-policy variant for A/B runs (tools/build_variant.py).
+#ifndef LS_GEMM_NT
+#define LS_GEMM_NT 1
+#endif
+template <typename V>
+__device__ __forceinline__ V load_w(const char* p) {
+#if LS_GEMM_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#else
+    return *reinterpret_cast<const V*>(p);
+#endif
 }
 
 // MT = 16-row tiles of x (M <= 16*MT); NT = 16-row weight tiles per workgroup (4: one packed slab, 8: two)
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wa[set][kk][t] = *reinterpret_cast<const V8*>(wtile[t] + (long)(ch * 2 + kk) * 4096);
+            for (int t = 0; t < NT; ++t) wa[set][kk][t] = load_w<V8>(wtile[t] + (long)(ch * 2 + kk) * 4096);
     };
     auto mma_chunk = [&](int set) {
 #pragma unroll
@@ -300,11 +323,10 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
             for (int h = 0; h < NPASS; ++h)
 #pragma unroll
                 for (int q = 0; q < NT_OUT; ++q) {
-                    float* mine = p.part + (((long)split * p.nslabs + slab) * NT + tile_of(h, q)) * TILE_F;
+                    const __amdgpu_buffer_rsrc_t mine =
+                        part_rsrc(p.part + (((long)split * p.nslabs + slab) * NT + tile_of(h, q)) * TILE_F, TILE_F * 4);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) st_coherent(mine + (mt * 4 + e) * 64 + lane, r[h][q][mt][e]);
+                    for (int mt = 0; mt < MT; ++mt) st_coherent4(mine, (mt * 64 + lane) * 16, r[h][q][mt]);
                 }
         }
         // Every thread drains its OWN write-through (sc1) partial stores before the barrier: only then may thread 0
@@ -333,11 +355,10 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
                 for (int h = 0; h < NPASS; ++h)
 #pragma unroll
                     for (int q = 0; q < NT_OUT; ++q) {
-                        const float* src = p.part + (((long)s * p.nslabs + slab) * NT + tile_of(h, q)) * TILE_F;
+                        const __amdgpu_buffer_rsrc_t src =
+                            part_rsrc(p.part + (((long)s * p.nslabs + slab) * NT + tile_of(h, q)) * TILE_F, TILE_F * 4);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) r[h][q][mt][e] += ld_coherent(src + (mt * 4 + e) * 64 + lane);
+                        for (int mt = 0; mt < MT; ++mt) r[h][q][mt] += ld_coherent4(src, (mt * 64 + lane) * 16);
                     }
             }
         }

@@ -284,16 +284,24 @@ class KVShard:
         if self._head.get("key") != key:
             w = lm_head.weight[lo:hi]
             self._head = {"key": key, "w": w, "packed": ops.pack_weight(w) if hi > lo and hasattr(ops, "topk_stage1") else None}
-        if hasattr(ops, "topk_stage1") and x.is_cuda:
-            kk = 1 if argmax else k
+        kk = 1 if argmax else k
+        nchunks = (V + self.VOCAB_CHUNK - 1) // self.VOCAB_CHUNK
+        # stage 2's candidate budget (csrc/topk.hip::stage2; the same test ops.logprob_topk makes before it falls back to the
+        # library): counted on the REAL chunks -- the slots past the vocabulary (world * ncl - nchunks of them, all at the end
+        # of the rank-ordered records) are dropped before stage 2, so a W-rank call has exactly the one-GPU call's budget
+        fits = V % 8 == 0 and (argmax or (kk <= 64 and rows <= 128 and rows * nchunks * kk <= 5120 and rows * nchunks <= 512))
+        if hasattr(ops, "topk_stage1") and x.is_cuda and fits:
             n = ncl * rows * (2 + 2 * kk)
             send, recv = self.buffers(n, x.device)
-            local = ops.linear(x, self._head["packed"]) if hi > lo else None
+            # n_splits=1: the full lm_head (>= 256 row groups) is never split in K, and a slice must keep that summation
+            # order whatever its own row count suggests to the launch planner -- else the logits depend on the world size
+            local = ops.linear(x, self._head["packed"], n_splits=1) if hi > lo else None
             ops.topk_stage1(local, rows, kk, lo, ncl, send, dtype=x.dtype)
             allrec = self.exchange(send, recv)[:, :n].reshape(self.world * ncl, rows, 2 + 2 * kk)
             if not allrec.is_contiguous():
                 allrec = allrec.contiguous()
-            return ops.topk_stage2(allrec, rows, V, kk, history.reshape(-1) if history is not None else None, argmax)
+            # an empty record adds exactly +0.0f to a row's sum and never holds a candidate: dropping it changes no bit
+            return ops.topk_stage2(allrec[:nchunks], rows, V, kk, history.reshape(-1) if history is not None else None, argmax)
         # generic form: all-gather the logits (equal widths: the short / empty slices are padded with -inf)
         width = ncl * self.VOCAB_CHUNK
         pad = torch.full((rows, width), float("-inf"), dtype=x.dtype, device=x.device)

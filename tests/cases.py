@@ -57,6 +57,25 @@ def verify_cases():
         yield d
 
 
+def decoding_torch_cases():
+    """G-h: outputs of the reference's own ``LlamaAttention.decoding_torch`` (longspec/test/llama.py:161-197) on seeded
+    inputs (tests/golden/make_golden.py::gen_decoding_torch)."""
+    g = load_golden("decoding_torch")
+    for i in range(int(g["n_cases"])):
+        t = f"c{i}"
+        H, Hkv, L, a, seed = (int(g[f"{t}_{k}"]) for k in ("H", "Hkv", "L", "a", "seed"))
+        q = toy.randn_f16((1, a, H, 128), seed * 13 + 0)
+        k = toy.randn_f16((1, a, Hkv, 128), seed * 13 + 1)
+        v = toy.randn_f16((1, a, Hkv, 128), seed * 13 + 2)
+        kc = torch.zeros(1, L + 16, Hkv, 128, dtype=torch.float16)
+        vc = torch.zeros(1, L + 16, Hkv, 128, dtype=torch.float16)
+        kc[:, :L] = toy.randn_f16((1, L, Hkv, 128), seed * 13 + 3)
+        vc[:, :L] = toy.randn_f16((1, L, Hkv, 128), seed * 13 + 4)
+        assert toy.checksum(q, k, v, kc, vc) == cksum_str(g[f"{t}_in_checksum"]), "RNG drift: regenerate goldens"
+        yield dict(name=t, H=H, Hkv=Hkv, L=L, a=a, q=q, k=k, v=v, kc=kc, vc=vc, out=_t(g[f"{t}_out"]),
+                   k_rows=_t(g[f"{t}_kcache_rows"]), v_rows=_t(g[f"{t}_vcache_rows"]))
+
+
 def draft_cases():
     """Each case: a draft self-attn KV cache with p valid rows, then step 0
     (a = 3 rows appended at p-2) and the four tree steps, chained on the same cache."""

@@ -252,6 +252,49 @@ def gen_dense_twin(llama, train_llama):
     save("verify_attention", n_cases=idx, have_dense=int(train_llama is not None), **arrays)
 
 
+
+# --------------------------------------------------------------------------- #
+# G-h: LlamaAttention.decoding_torch -- the reference's OWN dense decode step (longspec/test/llama.py:161-197), the twin of
+# the flash_attn_with_kvcache(causal=True) call of `decoding` (llama.py:304-329).  It pins the oracle's restatement of the
+# flash-attn contract (oracle/ref_ops.py::kvcache_attention) and the HIP prefix/append path to an output the reference
+# itself produced -- no stub of ours is on this path.
+# --------------------------------------------------------------------------- #
+def decoding_inputs(H, Hkv, L, a, seed):
+    q = toy.randn_f16((1, a, H, 128), seed * 13 + 0)
+    k = toy.randn_f16((1, a, Hkv, 128), seed * 13 + 1)
+    v = toy.randn_f16((1, a, Hkv, 128), seed * 13 + 2)
+    kc = torch.zeros(1, L + 16, Hkv, 128, dtype=torch.float16)
+    vc = torch.zeros(1, L + 16, Hkv, 128, dtype=torch.float16)
+    kc[:, :L] = toy.randn_f16((1, L, Hkv, 128), seed * 13 + 3)
+    vc[:, :L] = toy.randn_f16((1, L, Hkv, 128), seed * 13 + 4)
+    return q, k, v, kc, vc
+
+
+def gen_decoding_torch(llama):
+    arrays = {}
+    idx = 0
+    for (H, Hkv, L, a) in ((4, 2, 50, 3), (4, 1, 300, 1), (8, 2, 777, 5), (2, 2, 1024, 4), (4, 1, 37, 2), (8, 1, 2100, 1)):
+        seed = 9000 + idx
+        q, k, v, kc, vc = decoding_inputs(H, Hkv, L, a, seed)
+        ns = SimpleNamespace(K_Cache=kc.clone().permute(0, 2, 1, 3).contiguous(),          # decoding_torch's layout [b, Hkv, len, D]
+                             V_Cache=vc.clone().permute(0, 2, 1, 3).contiguous(),
+                             num_heads=H, num_key_value_heads=Hkv, num_key_value_groups=H // Hkv, head_dim=128,
+                             hidden_size=H * 128, softmax_scale=1 / (128 ** 0.5),
+                             q_proj=lambda x, q=q: q.reshape(1, a, -1), k_proj=lambda x, k=k: k.reshape(1, a, -1),
+                             v_proj=lambda x, v=v: v.reshape(1, a, -1), o_proj=lambda x: x)
+        cos = torch.ones(1, a, 128, dtype=torch.float16)
+        sin = torch.zeros(1, a, 128, dtype=torch.float16)
+        hidden = torch.zeros(1, a, H * 128, dtype=torch.float16)
+        out = llama.LlamaAttention.decoding_torch(ns, hidden, (cos, sin), L)
+        t = f"c{idx}"
+        arrays.update({f"{t}_H": H, f"{t}_Hkv": Hkv, f"{t}_L": L, f"{t}_a": a, f"{t}_seed": seed,
+                       f"{t}_in_checksum": np.frombuffer(toy.checksum(q, k, v, kc, vc).encode(), dtype=np.uint8),
+                       f"{t}_out": out.view(1, a, H, 128),
+                       f"{t}_kcache_rows": ns.K_Cache[:, :, L:L + a].permute(0, 2, 1, 3).contiguous(),
+                       f"{t}_vcache_rows": ns.V_Cache[:, :, L:L + a].permute(0, 2, 1, 3).contiguous()})
+        idx += 1
+    save("decoding_torch", n_cases=idx, **arrays)
+
 # --------------------------------------------------------------------------- #
 # G-d: tree_verification
 # --------------------------------------------------------------------------- #
@@ -738,6 +781,9 @@ def main():
     if "--only-chain-stochastic" in sys.argv:
         gen_chain_stochastic(llama, llama_glide)
         return
+    if "--only-decoding-torch" in sys.argv:
+        gen_decoding_torch(llama)
+        return
     if "--only-qwen2-bf16" in sys.argv:
         gen_generate(llama, llama_glide, family="qwen2_bf16")
         return
@@ -748,6 +794,7 @@ def main():
     gen_tree_verification(llama_glide)
     gen_target_tree_part(llama)
     gen_dense_twin(llama, train_llama)
+    gen_decoding_torch(llama)
     gen_generate(llama, llama_glide)
     gen_generate(llama, llama_glide, family="qwen2")
     gen_baselines(llama, llama_glide)

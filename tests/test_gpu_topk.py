@@ -65,7 +65,10 @@ def test_argmax_rows(R, V):
 
 
 @pytest.mark.parametrize("R,V,k,W", [(1, 128256, 4, 8), (16, 128256, 16, 8), (16, 128256, 16, 3), (4, 152064, 16, 2), (16, 32000, 16, 8),
-                                     (74, 128256, 1, 8), (74, 152064, 1, 2), (16, 512, 16, 2)])
+                                     (74, 128256, 1, 8), (74, 152064, 1, 2), (16, 512, 16, 2),
+                                     # world sizes whose slot count (W * ceil(chunks / W)) exceeds the one-GPU chunk count: the empty
+                                     # slots are dropped before stage 2, as dist.KVShard.head_select does
+                                     (16, 152064, 16, 8), (16, 152064, 16, 3), (16, 128256, 16, 7)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_vocabulary_parallel_stages_are_bit_identical(R, V, k, W, dtype):
     """Round 3 (the lm_head sharded by vocabulary, dist.KVShard.head_select): stage 1 on each rank's slice of the logits, the
@@ -92,8 +95,56 @@ def test_vocabulary_parallel_stages_are_bit_identical(R, V, k, W, dtype):
         recs.append(ops.topk_stage1(local, R, k, lo, ncl, buf, dtype=dtype).clone())
     allrec = torch.cat(recs, dim=0).contiguous()
     assert allrec.shape == (W * ncl, R, 2 + 2 * k) and not torch.isnan(allrec[..., 0::2]).any()      # (odd fields past 1 are int columns)
-    got = ops.topk_stage2(allrec, R, V, k, hist.reshape(-1) if hist is not None else None, argmax)
+    nchunks = (V + KVShard.VOCAB_CHUNK - 1) // KVShard.VOCAB_CHUNK
+    got = ops.topk_stage2(allrec[:nchunks], R, V, k, hist.reshape(-1) if hist is not None else None, argmax)
     if argmax:
         assert torch.equal(got, want)
+    else:
+        assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("R,V,k,W", [(16, 152064, 16, 8), (16, 152064, 16, 3), (16, 128256, 16, 7), (16, 128256, 16, 8),
+                                     (74, 128256, 1, 8), (16, 32000, 16, 2), (4, 152064, 16, 6)])
+def test_head_select_end_to_end_equals_the_one_gpu_head(R, V, k, W):
+    """ADVICE r3 (medium + low): ``KVShard.head_select`` itself -- sliced lm_head GEMM, stage 1, exchange, stage 2 -- against
+    ``ops.linear`` on the FULL weight followed by the one-GPU selection, for world sizes whose slot count exceeds the one-GPU
+    chunk count (QwQ at 3 / 6 / 8 ranks, Llama-3 at 7) and for slices whose own row count would make the launch planner split
+    K (Llama-3's 13568-column tail at 8 ranks, Vicuna's 16000 columns at 2): tokens must not depend on the world size.  The W
+    ranks are simulated in one process: every rank's send buffer is captured, then rank 0 merges them."""
+    from longspec_amd import ops
+    from longspec_amd.dist import KVShard
+    Hd = 256
+    g = torch.Generator().manual_seed(7 * R + V + k + W)
+    lm = torch.nn.Linear(Hd, V, bias=False)
+    with torch.no_grad():
+        lm.weight.copy_(torch.randn(V, Hd, generator=g) * 0.05)
+    lm = lm.half().cuda()
+    x = torch.randn(1, R, Hd, generator=g).half().cuda()
+    argmax = k == 1
+    hist = None if argmax else (-torch.rand(1, R, generator=g) * 3).cuda()
+    full = ops.linear(x.view(R, Hd), ops.pack_weight(lm.weight))
+    want = ops.argmax_rows(full) if argmax else ops.logprob_topk(full.view(1, R, V), hist, k)
+    sends = []
+
+    class Capture(Exception):
+        pass
+
+    for r in range(W):
+        sh = KVShard(r, W, 16)
+
+        def grab(send, recv, _sh=sh):
+            sends.append(send.clone())
+            raise Capture()
+        sh.exchange = grab
+        try:
+            sh.head_select(lm, x, ops, k=k, history=hist, argmax=argmax)
+        except Capture:
+            pass
+    assert len(sends) == W
+    sh0 = KVShard(0, W, 16)
+    sh0.exchange = lambda send, recv: torch.stack(sends, dim=0)
+    got = sh0.head_select(lm, x, ops, k=k, history=hist, argmax=argmax)
+    if argmax:
+        assert torch.equal(got.view(-1), want.view(-1))
     else:
         assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
