@@ -263,9 +263,10 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
 }
 
 // Cache policy of the streamed prefix K/V (every byte is used once per call by one workgroup): -DLS_KV_NT=1 requests it
-// non-temporally (MI355X_MICROARCH "nt-weights"); 0 = default policy.
+// non-temporally (MI355X_MICROARCH "nt-weights"; round 4 A/B on one box: verification call 0.4114 -> 0.4175 of the HBM roofline,
+// round 12.28 -> 12.15 ms); 0 = default policy.
 #ifndef LS_KV_NT
-#define LS_KV_NT 0
+#define LS_KV_NT 1
 #endif
 #if LS_KV_NT
 #define LS_KV_POLICY " nt"

@@ -104,6 +104,10 @@ __device__ __forceinline__ f32x4 ld_coherent4(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef LS_GEMM_NT
 #define LS_GEMM_NT 1
 #endif
+// -DLS_GEMM_KSTEP8=0: the round-3 pipeline of the 128-row variant (one 16 KB chunk of look-ahead) for A/B runs
+#ifndef LS_GEMM_KSTEP8
+#define LS_GEMM_KSTEP8 1
+#endif
 template <typename V>
 __device__ __forceinline__ V load_w(const char* p) {
 #if LS_GEMM_NT
@@ -122,8 +126,15 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     using V4 = typename E::V4;
     // chunks (2 k-steps = 64 k; NT x 2 KB of W) of look-ahead per wave.  M <= 32: 2 waves per SIMD (256
     // registers each); above: 1 wave per SIMD with the full 512.
-    constexpr int LAC = NT == 8 ? 1 : MT == 1 ? 4 : 3;
-    constexpr int NCS = LAC + 1;             // W register sets, one per chunk in flight
+    // A W register set ("unit") holds KPS k-steps of the workgroup's NT tiles: a whole 64-k chunk (2 k-steps x 4 tiles) for
+    // the 64-row variants, ONE k-step x 8 tiles for the 128-row variant -- 32 registers either way, so that the 128-row
+    // launches (gate|up, lm_head) keep three sets = 24 KB per wave in flight like the others instead of one 16 KB chunk
+    // (round 4: they streamed at 5.2 TB/s against 5.9 for the 64-row launches of the same pass).
+    constexpr int KPS = (NT == 8 && LS_GEMM_KSTEP8) ? 1 : 2;
+    constexpr int UPC = 2 / KPS;             // units per 64-k chunk of x
+    constexpr int LAC = NT == 8 ? (KPS == 1 ? 3 : 1) : MT == 1 ? 4 : 3;      // units of look-ahead
+    constexpr int NCS = LAC + 1;             // W register sets, one per unit in flight
+    static_assert(NCS % UPC == 0, "the x-chunk phase of a unit must be static inside the unrolled loop");
     constexpr int XL = 2 * MT;               // 1 KB pieces (8 rows x 128 B) of one x chunk
     constexpr int XSLAB = MT * 16 * 128;     // bytes of a wave's x slab
     constexpr int NPASS = NT / 4;            // the 4-wave reduction handles 4 tiles per pass (LDS budget)
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     const int ch0 = ch_begin + wave * quarter;
     const int nch = max(0, min(ch_end - ch0, quarter));
 
-    V8 wa[NCS][2][NT];           // [chunk set][k-step in chunk][tile]
+    V8 wa[NCS][KPS][NT];         // [set][k-step in unit][tile]
     V8 xs[XL];                   // x staging: piece i = rows 8i .. 8i+7, lane -> (row 8i + lane/8, 16 B slot lane%8)
     char* xlds = smem + wave * XSLAB;
     const int xr_in = lane >> 3, xslot = lane & 7;
@@ -218,20 +229,23 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
             *reinterpret_cast<V8*>(xlds + row * 128 + ((xslot ^ ((row >> 1) & 7)) << 4)) = v;
         }
     };
-    auto issue_w = [&](int ch, int set) {
+    // unit `un` of this wave = k-steps ch0 * 2 + un * KPS ... of the slab
+    auto issue_w = [&](int un, int set) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < KPS; ++kk)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wa[set][kk][t] = load_w<V8>(wtile[t] + (long)(ch * 2 + kk) * 4096);
+            for (int t = 0; t < NT; ++t) wa[set][kk][t] = load_w<V8>(wtile[t] + (long)(ch0 * 2 + un * KPS + kk) * 4096);
     };
-    auto mma_chunk = [&](int set) {
+    // `ph` = the unit's position inside its x chunk (0 .. UPC - 1; static)
+    auto mma_unit = [&](int ph, int set) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KPS; ++kk) {
+            const int ks = ph * KPS + kk;                    // k-step inside the 64-k chunk staged in LDS
             V8 bx[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = mt * 16 + l15;
-                bx[mt] = *reinterpret_cast<const V8*>(xlds + row * 128 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 4));
+                bx[mt] = *reinterpret_cast<const V8*>(xlds + row * 128 + (((ks * 4 + g4) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -240,10 +254,11 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
         }
     };
 
+    const int nun = nch * UPC;                               // units of this wave
     if (nch > 0) load_x(ch0);
 #pragma unroll
     for (int i = 0; i < LAC; ++i)
-        if (i < nch) issue_w(ch0 + i, i);
+        if (i < nun) issue_w(i, i);
     if (NORM) {
         // behind the first weight requests: thread r sums row r's partials in slab order (the canonical order)
         float* rsw = reinterpret_cast<float*>(smem + p.flag_off + 16);
@@ -258,25 +273,29 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     int c = 0;
     // steady state: no control flow inside, so the compiler's in-order vmcnt counts stay exact;
     // sched_barrier(0) keeps the loads of the chunks ahead in front of the MFMAs of the current one
-    for (; c + NCS - 1 + LAC < nch; c += NCS) {
+    for (; c + NCS - 1 + LAC < nun; c += NCS) {            // `c` (a multiple of NCS, hence of UPC) counts units
 #pragma unroll
         for (int u = 0; u < NCS; ++u) {
-            store_x();                                   // chunk c+u: staging registers -> the wave's LDS slab
-            load_x(ch0 + c + u + 1);
-            issue_w(ch0 + c + u + LAC, (u + LAC) % NCS);
+            if (u % UPC == 0) {
+                store_x();                               // the chunk of unit c+u: staging registers -> the wave's LDS slab
+                load_x(ch0 + (c + u) / UPC + 1);         // (the last chunk of the wave is never in this loop: LAC >= UPC)
+            }
+            issue_w(c + u + LAC, (u + LAC) % NCS);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(u);
+            mma_unit(u % UPC, u);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
-    for (int u = 0; u < NCS + LAC - 1; ++u) {            // drain (`c` is a multiple of NCS)
-        if (c + u < nch) {
-            store_x();
-            if (c + u + 1 < nch) load_x(ch0 + c + u + 1);
-            if (c + u + LAC < nch) issue_w(ch0 + c + u + LAC, (u + LAC) % NCS);
+    for (int u = 0; u < NCS + LAC - 1; ++u) {            // drain
+        if (c + u < nun) {
+            if (u % UPC == 0) {
+                store_x();
+                if ((c + u) / UPC + 1 < nch) load_x(ch0 + (c + u) / UPC + 1);
+            }
+            if (c + u + LAC < nun) issue_w(c + u + LAC, (u + LAC) % NCS);
             __builtin_amdgcn_sched_barrier(0);
-            mma_chunk(u % NCS);
+            mma_unit(u % UPC, u % NCS);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
