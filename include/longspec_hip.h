@@ -197,6 +197,12 @@ size_t ls_linear_workspace_bytes(const ls_linear_desc* d);
  * are plain library GEMMs: prefill). */
 int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Cache hint for the launch `d` describes (no counterpart in the reference; writes nothing): the same grid requests the
+ * first `units` register sets (8 KB each) of every wave's weight stream with the default cache policy, so that they sit in
+ * the L2 of the XCD the matching workgroup of ls_linear_fwd(d) runs on.  Issued while a latency-bound kernel (RMSNorm,
+ * attention finish) occupies the stream, it takes the HBM ramp off the projection that follows. */
+int ls_linear_prefetch(const ls_linear_desc* d, int units, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- RMSNorm / RoPE (K8, K9) ------------------------------------------------ */
 
 /* LlamaRMSNorm.forward (transformers; imported at longspec/test/llama.py:36; vendored

@@ -73,6 +73,7 @@ SYMBOLS = {
     "ls_linear_pack_rope": (C.c_int, [_P, _P, _I, _I, _I, _P]),
     "ls_linear_workspace_bytes": (C.c_size_t, [C.POINTER(LinearDesc)]),
     "ls_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), _P, C.c_size_t, _P]),
+    "ls_linear_prefetch": (C.c_int, [C.POINTER(LinearDesc), _I, _P, C.c_size_t, _P]),
     "ls_topk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ls_logprob_topk": (C.c_int, [_P, _I, _I, _L, _I, _P, _I, _P, _P, _P, C.c_size_t, _P]),
     "ls_argmax_rows": (C.c_int, [_P, _I, _I, _L, _I, _P, _P, C.c_size_t, _P]),

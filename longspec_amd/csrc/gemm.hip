@@ -77,6 +77,7 @@ struct GemmK {
     const char* norm_w;          // [K] dtype
     float norm_eps;
     float* ssq_out;              // [M, N / 64] or null
+    int prefetch_units;          // > 0: ls_linear_prefetch -- every wave only REQUESTS its first units (default cache policy) and exits
 };
 
 enum { EPI_NONE = 0, EPI_SILU_MUL = 1, EPI_QKV_ROPE = 2 };
@@ -255,6 +256,21 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     };
 
     const int nun = nch * UPC;                               // units of this wave
+    if (p.prefetch_units > 0) {
+        // ls_linear_prefetch: pull the first units of every wave's weight stream into the L2 of the XCD that the matching
+        // workgroup of the real launch will run on (same grid, block b -> XCD b % 8 as observed; speed only), with the
+        // DEFAULT cache policy -- the later nt loads hit those lines
+        const int n = min(nun, p.prefetch_units);
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KPS; ++kk)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const V8 v = *reinterpret_cast<const V8*>(wtile[t] + (long)(ch0 * 2 + i * KPS + kk) * 4096);
+                    asm volatile("" : : "v"(v));
+                }
+        return;
+    }
     if (nch > 0) load_x(ch0);
 #pragma unroll
     for (int i = 0; i < LAC; ++i)
@@ -705,7 +721,7 @@ size_t ls_linear_workspace_bytes(const ls_linear_desc* d) {
     return pl.counter_bytes + pl.part_bytes;
 }
 
-int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+static int linear_launch(const ls_linear_desc* d, void* workspace, size_t workspace_bytes, void* stream, int prefetch_units) {
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc != LS_OK) return rc;
@@ -740,6 +756,7 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
     k.ssq_in = d->ssq_in;
     k.ssq_parts = d->ssq_parts;
     k.ssq_out = d->ssq_out;
+    k.prefetch_units = prefetch_units;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     if (d->dtype == LS_F16)
@@ -752,6 +769,15 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
                                               : launch_mt<ElemBF16, EPI_NONE>(k, pl, s);
     if (d->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s);
     return rc;
+}
+
+int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    return linear_launch(d, workspace, workspace_bytes, stream, 0);
+}
+
+int ls_linear_prefetch(const ls_linear_desc* d, int units, void* workspace, size_t workspace_bytes, void* stream) {
+    if (units < 1) LS_FAIL(LS_ERR_INVALID_ARG, "ls_linear_prefetch: units");
+    return linear_launch(d, workspace, workspace_bytes, stream, units);
 }
 
 }  // extern "C"

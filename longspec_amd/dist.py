@@ -253,7 +253,13 @@ class KVShard:
             return call.attend_peer(self.peer._x)
         send, recv = self.buffers(call.record_floats, call.device)
         call.partial(send)
-        return call.finish(self.exchange(send, recv))
+        xt = getattr(call, "xchg_timing", None)
+        if xt is not None:                        # (includes the local reduction's tail: the collective is not a kernel of ours)
+            xt[0].record()
+        out = call.finish(self.exchange(send, recv))
+        if xt is not None:
+            xt[1].record()
+        return out
 
 
     # ---- the lm_head, sharded by vocabulary ------------------------------------------------------

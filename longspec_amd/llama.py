@@ -218,6 +218,7 @@ class LlamaAttention(nn.Module):
         self.ops = ops
         self.kv_len_hint = None                          # host-side upper bound of cache_lens (grid sizing)
         self.timing = None                               # optional callable -> (start, stop) events (bench.py)
+        self.xchg_timing = None                          # the same around the exchange + merge of a sharded call
         self.shard = None                                # dist.KVShard when the prefix KV is sequence-sharded
 
     def _qkv(self, hidden_states, position_embeddings):
@@ -324,6 +325,8 @@ class LlamaAttention(nn.Module):
                 call = self.ops.sharded_verify_attention(q, k, v, self.K_Cache, self.V_Cache, sh.pass_len(cache_lens),
                                                          tree_mask_bits, self.last_layer, softmax_scale=self.softmax_scale,
                                                          kv_len_hint=sh.local_hint(self.kv_len_hint), **extra)
+                if self.xchg_timing is not None:
+                    call.xchg_timing = self.xchg_timing()
                 attn = sh.attend(call)
                 return self.o_proj(attn.view(bsz, q_len, self.hidden_size).to(hidden_states.dtype))
             extra = {"timing": self.timing()} if self.timing is not None else {}

@@ -265,6 +265,9 @@ class NormFold:
         self.weight, self.eps, self.ssq = weight, float(eps), ssq
 
 
+PREFETCH_PROBE = 0       # measurement switch (tools/bench_l2_prefetch.py), 0 in the product
+
+
 def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=None, residual=None, norm=None, ssq_out=False):
     _dev(x)
     K = x.shape[-1]
@@ -339,6 +342,11 @@ def _linear_call(x, weights, biases, epilogue, n_splits=0, timing=None, rope=Non
         _linear_need[key] = need
     stream = _stream()
     ws = _gemm_ws.get(x.device, need, stream)
+    if PREFETCH_PROBE > 0:          # tools/bench_l2_prefetch.py: what an L2-resident head of the weight stream is worth
+        ev = (d.ev_start, d.ev_stop)
+        d.ev_start, d.ev_stop = None, None
+        _C.check(lib.ls_linear_prefetch(C.byref(d), PREFETCH_PROBE, ws.data_ptr(), ws.numel(), stream), "ls_linear_prefetch")
+        d.ev_start, d.ev_stop = ev
     _C.check(lib.ls_linear_fwd(C.byref(d), ws.data_ptr(), ws.numel(), stream), "ls_linear_fwd")
     return (y, ssq) if ssq_out else y
 
@@ -714,6 +722,7 @@ class ShardedAttnCall:
         self.ws = _ws.get(device, nbytes)       # stream-ordered: stage 2 runs before the next call reuses it
         self.n_o = desc.b * desc.sq * desc.H * 128
         self.n_lse = desc.b * desc.H * desc.sq
+        self.xchg_timing = None                 # optional (start, stop) torch events around the exchange + merge (bench.py)
 
     @property
     def record_floats(self) -> int:
@@ -735,8 +744,12 @@ class ShardedAttnCall:
         d = self.d
         ws, n, st = self.ws.data_ptr(), self.ws.numel(), _stream()
         _C.check(lib.ls_attn_partial(C.byref(d), ws, n, st), "ls_attn_partial")
+        if self.xchg_timing is not None:
+            self.xchg_timing[0].record()
         _C.check(lib.ls_attn_reduce_push(C.byref(d), ws, n, xchg, st), "ls_attn_reduce_push")
         _C.check(lib.ls_attn_finish_xchg(C.byref(d), xchg, ws, n, st), "ls_attn_finish_xchg")
+        if self.xchg_timing is not None:
+            self.xchg_timing[1].record()
         return self.out
 
     def finish(self, gathered: torch.Tensor) -> torch.Tensor:

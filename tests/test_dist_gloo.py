@@ -89,7 +89,9 @@ def test_sequence_sharded_tree_decode_matches_single_process(world, run_name):
         assert (count, num) == (run["tree_count"], run["tree_num"])
 
 
-@pytest.mark.parametrize("world,run_name,vocab_chunk", [(2, "mixed", 128), (3, "gqa_mixed", 64), (3, "forced", 200)])
+# (8, "mixed", 48): the REAL world size of BASELINE configs[2] -- the 512 toy entries are 11 chunks of 48
+# dealt two per rank: rank 5 owns a 32-column remainder, ranks 6 and 7 own nothing, the rank-ordered merge sees 16 slots
+@pytest.mark.parametrize("world,run_name,vocab_chunk", [(2, "mixed", 128), (3, "gqa_mixed", 64), (3, "forced", 200), (8, "mixed", 48)])
 def test_vocabulary_parallel_lm_head_matches_single_process(world, run_name, vocab_chunk):
     """Round 3: under a shard every rank multiplies by ITS slice of the lm_head (whole chunks of the vocabulary, dealt in rank
     order; 512 toy entries in chunks of 128 / 64 / 200 -> 2, 3 and 1 chunk per rank, the last rank of the third case owning
@@ -122,7 +124,7 @@ def test_vocab_slices_tile_the_vocabulary():
             assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
-@pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree")])
+@pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree"), (8, "gqa_mixed")])
 def test_sequence_sharded_prefill_and_decode_match_single_process(world, run_name):
     """``tree_spec_generate(..., shard=...)`` prefills rank-locally (one K/V all-gather per layer) and
     decodes sharded; token ids and counters equal the single-process golden run on every rank."""
