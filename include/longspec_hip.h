@@ -103,6 +103,12 @@ const char* ls_attn_kernel_name(const ls_attn_desc* d);
  *      + triton_tree_part_fwd :309-329 (window prefix + Triton tree kernel + fp32 merge) [K5+K6] */
 int ls_attn_fwd(const ls_attn_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostic: workgroups (key split x kv head) that had to REDO their split since the last reset because a soft-max numerator
+ * left the fp16 range of the split's fixed reference (csrc/attn.hip: the reference is the maximum over the split's first 64
+ * keys; flash-attn's running maximum, SURVEY App. C, has no such event).  Synchronises the device; not for the decode path.
+ * Returns the count (and zeroes it when reset != 0), -1 on a HIP error. */
+long ls_attn_redo_count(int reset);
+
 /* Stage 1 only: writes partials into the workspace (multi-GPU path). */
 int ls_attn_partial(const ls_attn_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -64,6 +64,7 @@ SYMBOLS = {
     "ls_attn_num_parts": (C.c_int, [C.POINTER(AttnDesc)]),
     "ls_attn_kernel_name": (C.c_char_p, [C.POINTER(AttnDesc)]),
     "ls_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
+    "ls_attn_redo_count": (C.c_long, [_I]),
     "ls_attn_partial": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P]),
     "ls_attn_reduce_local": (C.c_int, [C.POINTER(AttnDesc), _P, C.c_size_t, _P, _P, _P]),
     "ls_attn_finish": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _I, _L, _L, _P, C.c_size_t, _P]),

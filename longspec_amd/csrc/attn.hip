@@ -40,6 +40,11 @@
 
 namespace {
 
+// Diagnostic (ls_attn_redo_count; tools/bench_attn.py --sink / --score-scale): how many (key split, kv head) workgroups had to
+// redo their split because a soft-max numerator left the fp16 range of the fixed reference.  Bumped on that rare path only.
+__device__ unsigned int g_attn_redo_count = 0;
+
+
 constexpr int D = LS_HEAD_DIM;      // 128
 constexpr int ROWB = D * 2;         // bytes per key row (fp16/bf16)
 constexpr float LOG2E = 1.4426950408889634f;
@@ -539,6 +544,7 @@ __device__ __forceinline__ void prefix_path(const AttnK& p, char* smem, int spli
         if (__any(pmax > 16384.f) && x.lane == 0) *redo_flag = 1;
         __syncthreads();
         const int redo = *redo_flag;
+        if (redo && x.tid == 0) atomicAdd(&g_attn_redo_count, 1u);
         __syncthreads();
         if (!redo) break;
     }
@@ -1095,6 +1101,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         __syncthreads();
         __syncthreads();                                   // (the O waves raise the flag in between)
         if (*redo_flag) {
+            if (tid == 0) atomicAdd(&g_attn_redo_count, 1u);
             __syncthreads();
             run_pass(1);
             run_pass(2);
@@ -1853,6 +1860,18 @@ const char* ls_attn_kernel_name(const ls_attn_desc* d) {
     if (validate(d)) return "invalid";
     const Cfg c = pick_cfg(d->H / d->Hkv * d->sq, ws_eligible(d), d->kv_len_hint >= 4096);
     return c.ws == 3 ? "attn_partial_w4_kernel" : c.ws == 2 ? "attn_partial_pp_kernel" : c.ws ? "attn_partial_ws_kernel" : "attn_partial_kernel";
+}
+
+long ls_attn_redo_count(int reset) {
+    // synchronises the device: a diagnostic, never called on the decode path
+    unsigned int v = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_redo_count), sizeof(v)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_redo_count), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return (long)v;
 }
 
 int ls_attn_partial(const ls_attn_desc* d, void* ws, size_t ws_bytes, void* stream) {

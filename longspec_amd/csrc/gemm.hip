@@ -105,9 +105,11 @@ __device__ __forceinline__ f32x4 ld_coherent4(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef LS_GEMM_NT
 #define LS_GEMM_NT 1
 #endif
-// -DLS_GEMM_KSTEP8=0: the round-3 pipeline of the 128-row variant (one 16 KB chunk of look-ahead) for A/B runs
+// -DLS_GEMM_KSTEP8=1: k-step-granular sets for the 128-row variant (24 KB per wave in flight instead of one 16 KB chunk of
+// look-ahead).  Round-4 A/B on one box: lm_head 202 vs 207 us, gate|up+SiLU 47.0 vs 45.4 us, GEMM per round 5.57-5.72 vs
+// 5.60-5.65 ms -- no gain: the 128-row launches are not limited by their look-ahead.  Default: the round-3 pipeline.
 #ifndef LS_GEMM_KSTEP8
-#define LS_GEMM_KSTEP8 1
+#define LS_GEMM_KSTEP8 0
 #endif
 template <typename V>
 __device__ __forceinline__ V load_w(const char* p) {

@@ -29,11 +29,14 @@ def g(t):
     return t.to(DEV) if torch.is_tensor(t) else t
 
 
-def assert_close_f16(got, want, atol=1.1e-3, frac=None, mean=1.5e-4, what=""):
+def assert_close_f16(got, want, atol=1.1e-3, frac=None, mean=5e-5, what=""):
     """Parity bar of SURVEY 8(d): every element within one fp16 ulp at the output's magnitude
     (1e-3 abs for |o| <~ 2), mean |diff| an order of magnitude below that; `frac` bounds the
     share of differing elements where the arithmetic order is pinned (not through the
-    flash-style prefix, whose P -> fp16 rounding depends on the split-local running max)."""
+    flash-style prefix, whose P -> fp16 rounding depends on the split-local running max).
+    Round 4: every call records what it observed (conftest.record_margin ->
+    profiles/r4_parity_margins.json) and the bounds below are max(1.5 x the observed maximum, one ulp of the dtype at the
+    tensor's magnitude): fp16 outputs differ by whole ulps, 9.77e-4 for |o| in [1, 2), so 1.1e-3 is "one ulp" there."""
     d = (got.float().cpu() - want.float().cpu()).abs()
     assert torch.isfinite(got.float()).all(), f"{what}: non-finite output"
     record_margin(what, d.max().item(), d.mean().item(), atol, mean)
@@ -72,7 +75,7 @@ def assert_close_rel(got, want, ulps=2.0, noise=5.0, bits=11, what=""):
 def test_rmsnorm_golden(ops, c):
     y = ops.rmsnorm(g(c["x"]), g(c["w"]), c["eps"])
     # fp32 reduction order differs from torch's: allow one fp16 ulp on a sliver of elements
-    assert_close_f16(y, c["y"], atol=4e-3, frac=0.002, mean=1e-5, what="rmsnorm")
+    assert_close_f16(y, c["y"], atol=1.5e-3, frac=0.002, mean=1e-6, what="rmsnorm")
 
 
 def test_rmsnorm_residual(ops):
@@ -82,7 +85,7 @@ def test_rmsnorm_residual(ops):
     y, s = ops.rmsnorm(g(x), g(w), 1e-5, residual=g(r))
     s_ref = r + x
     assert torch.equal(s.cpu(), s_ref)
-    assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=8e-3, frac=0.002, mean=1e-5, what="rmsnorm+res")
+    assert_close_f16(y, ref_ops.rmsnorm(s_ref, w, 1e-5), atol=3e-3, frac=0.002, mean=1e-6, what="rmsnorm+res")
 
 
 @pytest.mark.parametrize("rows,hidden", [(1, 4096), (74, 5120), (16, 8192), (5, 16384), (3, 24576), (7, 40), (80, 1000),
@@ -299,7 +302,7 @@ def test_bf16_prefix(ops):
     cl = torch.tensor([L], dtype=torch.int32)
     o_ref = ref_ops.kvcache_attention(q, kc, vc, cache_seqlens=cl)
     o = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), kv_len_hint=L)
-    assert_close_f16(o, o_ref, atol=8.5e-3, mean=1.2e-3, what="bf16")      # one bf16 ulp at |o| ~ 1
+    assert_close_f16(o, o_ref, atol=7.9e-3, mean=2e-4, what="bf16")      # one bf16 ulp at |o| in [1, 2); observed 1.95e-3 / 8.9e-5
 
 
 # --------------------------------------------------------------------------- #
@@ -344,7 +347,7 @@ def test_verify_attention_model_shapes_vs_oracle(ops, H, Hkv):
         kc_g, vc_g = g(kc), g(vc)
         out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), False,
                                    kv_len_hint=4096 + 37)
-        assert_close_f16(out, ref, atol=2.1e-3, what=f"H={H}")
+        assert_close_f16(out, ref, atol=1.2e-3, what=f"H={H}")          # observed 7.6e-4
         assert torch.equal(kc_g.cpu(), kc_r)
 
 
@@ -378,7 +381,7 @@ def test_prefix_with_late_dominant_keys(ops, H, Hkv, sq):
     for n_splits in (0, 1, 3):
         o, lse = ops.kvcache_attention(g(q), g(kc), g(vc), cache_seqlens=g(cl), return_softmax_lse=True, kv_len_hint=L,
                                        n_splits=n_splits)
-        assert_close_f16(o, o_ref, atol=2.1e-3, what=f"late keys, splits={n_splits}")
+        assert_close_f16(o, o_ref, atol=1.5e-3, what=f"late keys, splits={n_splits}")      # observed 9.8e-4
         assert (lse.cpu() - lse_ref).abs().max().item() <= 1e-4
 
 
@@ -426,7 +429,7 @@ def test_verify_attention_bf16_vs_oracle(ops, H, Hkv, L, last_layer):
     kc_g, vc_g = g(kc), g(vc)
     out = ops.verify_attention(g(q), g(k), g(v), kc_g, vc_g, g(cl), ops.pack_tree_mask(g(tm)), last_layer, kv_len_hint=L)
     assert out.dtype == torch.bfloat16
-    assert_close_f16(out, ref, atol=1.7e-2, mean=1.5e-3, what=f"bf16 H={H}/{Hkv}")
+    assert_close_f16(out, ref, atol=9.6e-3, mean=2e-4, what=f"bf16 H={H}/{Hkv}")      # observed 6.4e-3 / 9.7e-5; one bf16 ulp at |o| ~ 1 is 7.8e-3
     assert torch.equal(kc_g.cpu(), kc_r) and torch.equal(vc_g.cpu(), vc_r)
 
 
@@ -477,7 +480,7 @@ def test_prefill_attention_vs_oracle(ops, H, Hkv, L, window, start):
     kc[:, :start] = g(k[:, :start])
     vc[:, :start] = g(v[:, :start])
     out = ops.prefill_attention(g(q[:, start:]), g(k[:, start:]), g(v[:, start:]), kc, vc, window_left=window, start=start)
-    assert_close_f16(out, ref, atol=2.1e-3, what=f"prefill L={L} start={start}")
+    assert_close_f16(out, ref, atol=1.5e-3, what=f"prefill L={L} start={start}")      # observed 9.8e-4
     assert torch.equal(kc[:, :T].cpu(), k) and torch.equal(vc[:, :T].cpu(), v)
 
 
@@ -501,7 +504,7 @@ def test_sharded_long_prompt_prefill_matches_the_single_gpu_calls(ops):
     part = ops.prefill_attention(q[:, start:], k[:, start:], v[:, start:], kc2, vc2, start=start, total=T)
     cut_end = (start + CH - 1) // CH * CH
     assert torch.equal(part[:, cut_end - start:], whole[:, cut_end:]), "chunks behind the cut one: the same calls, the same bits"
-    assert_close_f16(part[:, :cut_end - start], whole[:, start:cut_end].cpu(), atol=2.1e-3, what="the chunk the shard boundary cuts")
+    assert_close_f16(part[:, :cut_end - start], whole[:, start:cut_end].cpu(), atol=1.1e-3, what="the chunk the shard boundary cuts")      # observed 6.1e-5
     assert torch.equal(kc2[:, :T], kc[:, :T]) and torch.equal(vc2[:, :T], vc[:, :T])
 
 
@@ -680,4 +683,4 @@ def test_decode_attention_vs_reference_decoding_torch(ops, c):
                                 causal=True, kv_len_hint=L)
     torch.cuda.synchronize()
     assert torch.equal(kc[:, L:L + a].cpu(), c["k_rows"]) and torch.equal(vc[:, L:L + a].cpu(), c["v_rows"])
-    assert_close_f16(out, c["out"], atol=1.1e-3, mean=1.7e-4, what=f"G-h {c['name']}")
+    assert_close_f16(out, c["out"], atol=1.1e-3, mean=1.7e-4, what=f"G-h {c['name']}")      # observed 7.3e-4 / 1.1e-4

@@ -39,6 +39,15 @@ def main():
     ap.add_argument("--head-major", action="store_true",
                     help="K/V stored [b, Hkv, S, 128] and passed as the permuted [b, S, Hkv, 128] view: every workgroup streams one "
                          "contiguous region instead of 256 B out of every 2 KB row")
+    ap.add_argument("--score-scale", type=float, default=1.0,
+                    help="multiply the prefix K by this factor: soft-max logits ~ N(0, scale^2) instead of N(0, 1) -- heavier tails, "
+                         "more keys far above the maximum of a split's first 64 keys (the kernel's fixed soft-max reference)")
+    ap.add_argument("--sink", action="store_true",
+                    help="attention-sink + recency pattern: keys 0-3 score +12 nats for every query, and the logits ramp up by 6 nats "
+                         "over the last 2048 keys of the prefix")
+    ap.add_argument("--hot-keys", type=int, default=0, metavar="N",
+                    help="N keys at pseudo-random positions score +14 nats for every query (a retrieval head): each lands behind "
+                         "the first 64 keys of some split and leaves the fp16 range of that split's reference")
     args = ap.parse_args()
     dev = "cuda"
     for L in args.L:
@@ -62,6 +71,27 @@ def main():
             kc = kc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
             vc = vc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
         q, k, v = q.to(dev), k.to(dev), v.to(dev)
+        if args.score_scale != 1.0:
+            kc[:, :L] *= args.score_scale
+        if args.sink or args.hot_keys:
+            # a direction every query shares: q <- q + a*u, k_hot <- k_hot + b*u with a*b*|u|^2*scale = the wanted logit offset
+            u = torch.zeros(128, dtype=torch.float32)
+            u[:16] = 1.0
+            a = 2.0
+            q = (q.float() + a * u.to(dev)).half()
+
+            def bump(rows, nats):
+                b = nats / (a * 16.0 / (128 ** 0.5))
+                kc[0, rows] = (kc[0, rows].float() + b * u.to(dev)).half()
+            if args.sink:
+                bump(torch.arange(0, 4, device=dev), 12.0)
+                ramp = torch.arange(max(0, L - 2048), L, device=dev)
+                bq = (6.0 * (ramp - ramp[0]).float() / max(1, len(ramp) - 1)) / (a * 16.0 / (128 ** 0.5))
+                kc[0, ramp] = (kc[0, ramp].float() + bq[:, None, None] * u.to(dev)).half()
+            if args.hot_keys:
+                gh = torch.Generator().manual_seed(99)
+                pos = torch.randint(0, L, (args.hot_keys,), generator=gh).to(dev)
+                bump(pos, 14.0)
         if args.zeros:
             for t in (q, k, v, kc, vc):
                 t.zero_()
@@ -76,6 +106,10 @@ def main():
         for _ in range(5):
             call()
         torch.cuda.synchronize()
+        from longspec_amd import _C
+        _C.load().ls_attn_redo_count(1)
+        call()
+        redo_per_call = _C.load().ls_attn_redo_count(1)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if args.round_like > 0:
             src = torch.empty(args.round_like * (1 << 20) // 2, dtype=torch.uint8, device=dev)
@@ -111,7 +145,8 @@ def main():
             us = s.elapsed_time(e) * 1e3 / args.iters
         by = algo_bytes(L, H, Hkv, R=args.sq)
         flops = 4 * args.sq * H * 128 * L
-        print(json.dumps({"mode": args.mode, "kv_gap": args.kv_gap, "head_major": args.head_major, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
+        print(json.dumps({"score_scale": args.score_scale, "sink": args.sink, "hot_keys": args.hot_keys,
+                          "redo_workgroups_per_call": int(redo_per_call), "mode": args.mode, "kv_gap": args.kv_gap, "head_major": args.head_major, "zeros": args.zeros, "gap_us": args.gap_us, "round_like_MB": args.round_like, "L": L, "H": H, "Hkv": Hkv, "sq": args.sq, "us_per_call": round(us, 2),
                           "algo_GBps": round(by / us / 1e3, 1), "frac_of_8TBps": round(by / us / 1e3 / 8000, 4),
                           "TFLOPs": round(flops / us / 1e6, 1)}))
 
