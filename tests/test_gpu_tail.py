@@ -1,0 +1,121 @@
+"""The persistent layer tail (ls_layer_tail_fwd) against the launch chain it replaces -- bit for bit -- and under repetition
+(the in-launch hand-offs must never serve a stale line: same buffers, new data every call, consumers L1-warm)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (hidden, inter, H, Hkv, qkv bias)   Llama-3-8B / Vicuna-7B (MHA) / QwQ-32B (Qwen2: q/k/v bias) / a toy
+DIMS = {"llama3-8b": (4096, 14336, 32, 8, False), "vicuna-7b": (4096, 11008, 32, 32, False), "qwq-32b": (5120, 27648, 40, 8, True),
+        "toy": (256, 512, 2, 2, False)}
+
+
+def _weights(g, hidden, inter, H, Hkv, bias, dtype):
+    from longspec_amd import ops
+    def w(n, k):
+        return (torch.randn(n, k, generator=g) * 0.03).to(dtype).to(DEV)
+    Wo, Wg, Wu, Wd = w(hidden, H * 128), w(inter, hidden), w(inter, hidden), w(hidden, inter)
+    Wq, Wk, Wv = w(H * 128, hidden), w(Hkv * 128, hidden), w(Hkv * 128, hidden)
+    bq = [(torch.randn(n, generator=g) * 0.1).to(dtype).to(DEV) if bias else None for n in (H * 128, Hkv * 128, Hkv * 128)]
+    n1 = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(DEV)
+    n2 = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(DEV)
+    return dict(o=ops.pack_weight(Wo), gu=ops.pack_gate_up(Wg, Wu), d=ops.pack_weight(Wd),
+                qkv=[ops.pack_weight(Wq, rope=True), ops.pack_weight(Wk, rope=True), ops.pack_weight(Wv)], bq=bq, n1=n1, n2=n2)
+
+
+def _chain(ops, W, attn, resid, cos, sin, eps, with_qkv):
+    y = ops.linear(attn, W["o"])
+    xn1, h1 = ops.rmsnorm(y, W["n1"], eps, residual=resid)
+    act = ops.mlp_gate_up(xn1, W["gu"])
+    y2 = ops.linear(act, W["d"])
+    xn2, h2 = ops.rmsnorm(y2, W["n2"], eps, residual=h1)
+    qkv = torch.cat(ops.linear_qkv_rope(xn2, W["qkv"], W["bq"], cos, sin), dim=-1) if with_qkv else None
+    return h2, xn2, qkv
+
+
+@pytest.mark.parametrize("model,M,dtype,with_qkv", [("llama3-8b", 74, torch.float16, True), ("llama3-8b", 74, torch.float16, False),
+                                                    ("llama3-8b", 80, torch.bfloat16, True), ("llama3-8b", 33, torch.float16, True),
+                                                    ("vicuna-7b", 74, torch.float16, True), ("qwq-32b", 74, torch.bfloat16, True),
+                                                    ("toy", 74, torch.float16, True), ("toy", 41, torch.float16, False)])
+def test_layer_tail_equals_the_launch_chain(model, M, dtype, with_qkv):
+    from longspec_amd import ops
+    hidden, inter, H, Hkv, bias = DIMS[model]
+    assert ops.layer_tail_supported(M, hidden, inter, dtype, Ko=H * 128, n_qkv=(H * 128, Hkv * 128, Hkv * 128))
+    g = torch.Generator().manual_seed(hidden + inter + M)
+    W = _weights(g, hidden, inter, H, Hkv, bias, dtype)
+    eps = 1e-5
+    pos = torch.arange(1000, 1000 + M, dtype=torch.int64, device=DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128)).to(DEV)
+    cos, sin = ops.rope_cos_sin(pos[None], inv, 1.0, dtype)
+    cos, sin = cos.reshape(M, 128).contiguous(), sin.reshape(M, 128).contiguous()
+    for it in range(12 if model != "qwq-32b" else 4):
+        attn = torch.randn(M, H * 128, generator=g).to(dtype).to(DEV)
+        resid = torch.randn(M, hidden, generator=g).to(dtype).to(DEV)
+        h2, xn2, qkv = _chain(ops, W, attn, resid, cos, sin, eps, with_qkv)
+        r = resid.clone()
+        xn, qkv_f = ops.layer_tail(attn, r, W["o"], W["n1"], W["gu"], W["d"], W["n2"], eps,
+                                   qkv_weights=W["qkv"] if with_qkv else None, qkv_biases=W["bq"] if with_qkv else None,
+                                   cos=cos if with_qkv else None, sin=sin if with_qkv else None)
+        torch.cuda.synchronize()
+        assert torch.equal(r, h2), f"iteration {it}: residual stream differs ({(r.float() - h2.float()).abs().max().item():.3e})"
+        assert torch.equal(xn, xn2), f"iteration {it}: normalised rows differ ({(xn.float() - xn2.float()).abs().max().item():.3e})"
+        if with_qkv:
+            assert torch.equal(qkv_f, qkv), f"iteration {it}: q|k|v differ ({(qkv_f.float() - qkv.float()).abs().max().item():.3e})"
+    ops.layer_tail_check()
+
+
+def test_layer_tail_under_load_and_replayed_from_a_graph():
+    """32 tail launches back to back on changing data (a verification pass's worth), once eagerly and once replayed from a
+    HIP graph (the launch generation lives in device memory: a replay must advance it like a launch), with a bandwidth hog
+    on a second stream while the eager run is in flight (uneven arrival at the in-launch counters)."""
+    from longspec_amd import ops
+    hidden, inter, H, Hkv, bias = DIMS["llama3-8b"]
+    M, dtype, eps = 74, torch.float16, 1e-5
+    g = torch.Generator().manual_seed(5)
+    W = _weights(g, hidden, inter, H, Hkv, bias, dtype)
+    pos = torch.arange(5000, 5000 + M, dtype=torch.int64, device=DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128)).to(DEV)
+    cos, sin = ops.rope_cos_sin(pos[None], inv, 1.0, dtype)
+    cos, sin = cos.reshape(M, 128).contiguous(), sin.reshape(M, 128).contiguous()
+    attn0 = torch.randn(M, H * 128, generator=g).to(dtype).to(DEV)
+    resid0 = torch.randn(M, hidden, generator=g).to(dtype).to(DEV)
+
+    def run(fused, n=32):
+        resid, attn = resid0.clone(), attn0.clone()
+        outs = []
+        for _ in range(n):
+            if fused:
+                xn, qkv = ops.layer_tail(attn, resid, W["o"], W["n1"], W["gu"], W["d"], W["n2"], eps, qkv_weights=W["qkv"],
+                                         qkv_biases=W["bq"], cos=cos, sin=sin)
+            else:
+                resid, xn, qkv = _chain(ops, W, attn, resid, cos, sin, eps, True)
+            attn = qkv[:, :H * 128].contiguous()          # feed the next "layer" with this one's q rows
+            outs.append(qkv)
+        return resid, xn, outs
+
+    want = run(False)
+    hog_src = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            hog_dst.copy_(hog_src)
+    got = run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert all(torch.equal(a, b) for a, b in zip(got[2], want[2]))
+    # the same 32 launches captured once and replayed twice
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(True, 2)                                       # warm-up on the capture stream (workspace, plan caches)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            cap = run(True)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap[0], want[0]) and torch.equal(cap[1], want[1])
+        assert all(torch.equal(a, b) for a, b in zip(cap[2], want[2]))
+    ops.layer_tail_check()
