@@ -796,6 +796,10 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
 // true row maxima, then the same loop with those.  K and V stream through separate rings of 32-key blocks
 // (global_load_lds from all 8 waves, one K and one V piece per wave and step): block b is issued LA steps
 // before its K is multiplied (step b-1) and its V slot is released two steps later.
+#ifndef LS_WS_HEADROOM
+#define LS_WS_HEADROOM 4
+#endif
+constexpr int WS_HEADROOM = LS_WS_HEADROOM;     // octaves between the first-64-keys maximum and the fixed soft-max reference
 constexpr int WS_QT = 5;                         // row tiles per pair
 constexpr int WS_LA = 5;                         // blocks of DMA look-ahead (80 KB of K+V in flight per CU)
 constexpr int WS_NK = WS_LA + 1;                 // K ring stages: block b lives from step b-1-LA to step b-1
@@ -984,6 +988,17 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 qk_block<E, QT>(s_cur, qf, tb, k_addr(0));
                 mask_tail(s_cur, 0);
                 if (mode == 0) row_max(s_cur, mref);
+            }
+            if (mode == 0) {
+                // Head-room (round 4): the fixed reference sits WS_HEADROOM octaves ABOVE the maximum of the first 64 keys, so a
+                // later key may exceed that maximum by (16 + WS_HEADROOM) octaves before its numerator leaves the fp16 range
+                // and the split is redone.  All numerators, their fp16 roundings and the row sums scale by exactly 2^-WS_HEADROOM
+                // (only values within WS_HEADROOM octaves of the smallest normal number -- weights below 2^-(14 - WS_HEADROOM)
+                // of the first-64 maximum -- lose bits earlier), o = acc / l and lse = m * scale + ln(l) do not move.  Measured
+                // (profiles/r4_redo_*.json): 8 retrieval-style keys 14 nats above the bulk redo 64 workgroups of a 128k call
+                // (427 us instead of 226) at WS_HEADROOM 0 and none at 4.
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mref[qt] += (float)WS_HEADROOM / c;        // (-inf stays -inf)
             }
             if (mode != 1) {
 #pragma unroll

@@ -35,6 +35,7 @@
 // LlamaMLP.forward (transformers; vendored qwen2.py:218-230), llama_glide.py:248-250,268,285-287,305
 // (draft projections), lm_head at llama_glide.py:960,1019,1046,1091.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ls_common.h"
 
@@ -571,7 +572,17 @@ struct TailK {
     unsigned* sync;                           // [0] generation, [1] error latch, counters from word 16 on (64 B apart)
     unsigned spin_limit;
     int flag_off;
+    int n1_rows, n2_rows;                     // rows per workgroup of the two norm phases (1, 2 or 4)
+    int l2_units;                             // units (8 KB per wave) of seam-time L2 prefetch behind the register sets; 0 = off
+    int l2_scratch_off;                       // LDS byte offset of the 1 KB DMA scratch slot
+    unsigned long long* prof;                 // -DLS_TAIL_PROF (tools/tail_prof.py): [G][16] s_memrealtime stamps, else unused
 };
+
+#ifdef LS_TAIL_PROF
+#define TAIL_STAMP(i) do { if (threadIdx.x == 0) p.prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_STAMP(i)
+#endif
 
 __device__ __forceinline__ unsigned* tail_counter(unsigned* sync, int k, int shard) { return sync + 16 + (k * 8 + shard) * 16; }
 
@@ -623,7 +634,7 @@ struct TailCore {
     struct Geo {
         const char* wtile[NT];
         const char* bias_p;
-        int ch0, nch, nun;
+        int ch0, nch, nun, quarter;
         int seg, seg_base, n_lim, n_tile0;
     };
 
@@ -657,6 +668,7 @@ struct TailCore {
         g.ch0 = ch_begin + wave * quarter;
         g.nch = max(0, min(ch_end - g.ch0, quarter));
         g.nun = g.nch * UPC;
+        g.quarter = quarter;
     }
 
     static __device__ __forceinline__ void issue_w(V8 (&pool)[32], const Geo& g, int un, int set) {
@@ -671,6 +683,34 @@ struct TailCore {
 #pragma unroll
         for (int i = 0; i < LAC; ++i)
             if (i < g.nun) issue_w(pool, g, i, i);
+    }
+
+    // Behind the register sets: `nu` more units of the item's stream are pulled into the XCD's L2 while the workgroup sits at
+    // a seam (the seams take ~10 us -- two counter hops and a norm phase -- and 24 KB per wave of register look-ahead cover 4
+    // of them).  The requests are LDS-DMA writes into a 1 KB scratch slot that nobody reads: no destination register to keep
+    // alive, default cache policy, so the stream's later nt loads hit.  Wave 0 polls the counters -- its own requests would
+    // queue in front of every poll -- so waves 1..3 also touch wave 0's units (unit u by wave 1 + u % 3).
+    static __device__ __forceinline__ void prefetch_l2(const Geo& g, int wave, int quarter_chunks, unsigned lds_scratch, int nu) {
+        auto touch = [&](const char* src) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_scratch) : "memory", "m0");
+        };
+        if (wave == 0) return;
+        for (int i = 0; i < nu; ++i) {
+            const int un = LAC + i;
+            if (un < g.nun) {
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) touch(g.wtile[t] + (long)(g.ch0 * 2 + un * KPS + kk) * 4096);
+            }
+            if (un < g.nun && wave == 1 + i % 3) {           // wave 0's unit `un`: its k-range starts `wave` quarters earlier
+                const int ch0_w0 = g.ch0 - wave * quarter_chunks;
+#pragma unroll
+                for (int kk = 0; kk < KPS; ++kk)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) touch(g.wtile[t] + (long)(ch0_w0 * 2 + un * KPS + kk) * 4096);
+            }
+        }
     }
 
     static __device__ __forceinline__ void mainloop(V8 (&pool)[32], const Geo& g, const char* x, long ldx, int M, char* xlds,
@@ -749,17 +789,22 @@ struct TailCore {
 // one row of N1 / N2: y = dtype(sum of the S split partials, split order); h = dtype(residual + y) -> residual stream;
 // xn = norm_w * dtype(h32 * rsqrt(mean(h32^2) + eps)) -> write-through.  rmsnorm_rows_kernel's arithmetic (canonical sum of
 // squares, ls_common.h), the split sum of skinny_gemm_kernel's last arriver.
-template <typename E>
-__device__ __forceinline__ void tail_norm_row(const TailK& p, int S, int row, const char* norm_w, char* smem, int tid) {
+// T threads per row: a workgroup handles 256 / T rows side by side (row0 + tid / T; rows >= M idle along).
+template <typename E, int T>
+__device__ __forceinline__ void tail_norm_row(const TailK& p, int S, int row0, const char* norm_w, char* smem, int tid_wg) {
     using V8 = typename E::V8;
-    constexpr int NCH = 4;                                   // hidden <= 8192
+    constexpr int NCH = 8192 / (8 * T);                      // hidden <= 8192
     const int hidden = p.hidden;
-    float* slab_s = reinterpret_cast<float*>(smem);          // hidden / 64 slab sums
+    const int tid = tid_wg % T;
+    const int row_raw = row0 + tid_wg / T;
+    const bool live = row_raw < p.M;
+    const int row = live ? row_raw : p.M - 1;                // (an idle group recomputes the last row and stores nothing)
+    float* slab_s = reinterpret_cast<float*>(smem) + (tid_wg / T) * 128;      // hidden / 64 slab sums of this group's row
     V8 h[NCH], w8[NCH];
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xn, 0, p.M * hidden * 2, 0x00020000);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int i = (c * GEMM_THREADS + tid) * 8;
+        const int i = (c * T + tid) * 8;
         float s8 = 0.f;
         if (i < hidden) {
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
@@ -775,7 +820,7 @@ __device__ __forceinline__ void tail_norm_row(const TailK& p, int S, int row, co
                 h[c][e] = E::from_f32(E::to_f32(r[e]) + round_to<E>(a[e]));
                 h[c][4 + e] = E::from_f32(E::to_f32(r[4 + e]) + round_to<E>(b[e]));
             }
-            *reinterpret_cast<V8*>(p.resid + ((long)row * p.ld_res + i) * 2) = h[c];
+            if (live) *reinterpret_cast<V8*>(p.resid + ((long)row * p.ld_res + i) * 2) = h[c];
             s8 = ssq_quad(E::to_f32(h[c][0]), E::to_f32(h[c][1]), E::to_f32(h[c][2]), E::to_f32(h[c][3])) +
                  ssq_quad(E::to_f32(h[c][4]), E::to_f32(h[c][5]), E::to_f32(h[c][6]), E::to_f32(h[c][7]));
         }
@@ -789,8 +834,8 @@ __device__ __forceinline__ void tail_norm_row(const TailK& p, int S, int row, co
     const float rs = rsqrtf(tot / (float)hidden + p.eps);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int i = (c * GEMM_THREADS + tid) * 8;
-        if (i < hidden) {
+        const int i = (c * T + tid) * 8;
+        if (i < hidden && live) {
             V8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -821,8 +866,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
     V8 pool[32];
     char* xlds = smem + wave * C4::XSLAB;
     float* red = reinterpret_cast<float*>(smem);
-    const bool norm_wg = wg >= G - p.M;
-    const int norm_row = wg - (G - p.M);
+    // N1 / N2: the last ceil(M / R) workgroups normalise R rows each (R = p.n1_rows / p.n2_rows in {1, 2, 4}: with more rows
+    // per workgroup the phase fits into the workgroups that have no item of the projection behind it)
+    const int n1_wgs = (p.M + p.n1_rows - 1) / p.n1_rows, n2_wgs = (p.M + p.n2_rows - 1) / p.n2_rows;
+    const bool norm1_wg = wg >= G - n1_wgs, norm2_wg = wg >= G - n2_wgs;
+    auto norm_rows = [&](int S, int rows_per_wg, int first_wg, const char* nw) {
+        const int row0 = (wg - first_wg) * rows_per_wg;
+        if (rows_per_wg == 1) tail_norm_row<E, 256>(p, S, row0, nw, smem, tid);
+        else if (rows_per_wg == 2) tail_norm_row<E, 128>(p, S, row0, nw, smem, tid);
+        else tail_norm_row<E, 64>(p, S, row0, nw, smem, tid);
+    };
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const unsigned l2_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)(smem + p.l2_scratch_off));
 
     // the 4 waves' accumulators of 4 tiles -> LDS -> wave w sums tile 4h + w (plain) or the pair 4h + 2w, 4h + 2w + 1 (waves 0, 1)
     auto reduce_plain = [&](const f32x4 (&acc)[4][MT], f32x4 (&r)[MT]) {
@@ -865,8 +920,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
     };
 
     // ---------------- P1: o_proj ----------------
+    TAIL_STAMP(0);
     partial_phase(p.o, p.attn, p.ld_attn, false);
+    TAIL_STAMP(1);
     tail_arrive(p.sync, 0);
+    TAIL_STAMP(2);
     // ---------------- N1 ----------------
     typename CG::Geo gg;
     bool pre_g = false;
@@ -874,13 +932,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
         if (wg < p.gu.nslabs) {
             CG::geo(p.gu, true, wg, 0, wave, lane, gg);
             CG::prefetch(pool, gg);
+            CG::prefetch_l2(gg, wave, gg.quarter, l2_scratch, p.l2_units * (GU8 ? 2 : 1));      // (one-k-step units are half as large)
             pre_g = true;
         }
     };
-    if (norm_wg) {
+    if (norm1_wg) {
         tail_wait(p.sync, 0, target, p.spin_limit, wave, lane);
-        tail_norm_row<E>(p, p.o.S, norm_row, p.norm1_w, smem, tid);
+        TAIL_STAMP(3);
+        norm_rows(p.o.S, p.n1_rows, G - n1_wgs, p.norm1_w);
         tail_arrive(p.sync, 1);
+        TAIL_STAMP(4);
         prefetch_gu();
     } else {
         tail_arrive(p.sync, 1);                              // nothing to publish: counted in before the requests below
@@ -889,6 +950,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
     // ---------------- P2: gate|up + SiLU ----------------
     {
         tail_wait(p.sync, 1, target, p.spin_limit, wave, lane);
+        TAIL_STAMP(5);
         for (int item = wg; item < p.gu.nslabs; item += G) {
             if (!pre_g) CG::geo(p.gu, true, item, 0, wave, lane, gg);
             f32x4 acc[NTG][MT];
@@ -931,7 +993,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
             }
             __syncthreads();
         }
+        TAIL_STAMP(6);
         tail_arrive(p.sync, 2);
+        TAIL_STAMP(7);
     }
     // ---------------- P3: down_proj ----------------
     {
@@ -940,11 +1004,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
         if (wg < p.down.nslabs * p.down.S) {
             C4::geo(p.down, false, wg % p.down.nslabs, wg / p.down.nslabs, wave, lane, g3);
             C4::prefetch(pool, g3);
+            C4::prefetch_l2(g3, wave, g3.quarter, l2_scratch, p.l2_units);
             pre3 = true;
         }
         tail_wait(p.sync, 2, target, p.spin_limit, wave, lane);
+        TAIL_STAMP(8);
         partial_phase(p.down, p.act, p.inter, pre3);
+        TAIL_STAMP(9);
         tail_arrive(p.sync, 3);
+        TAIL_STAMP(10);
     }
     // ---------------- N2 (+ P4's first requests) ----------------
     const bool has_q = p.qkv != nullptr;
@@ -954,13 +1022,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
         if (has_q && wg < p.q.nslabs * p.q.S) {
             C4::geo(p.q, false, wg % p.q.nslabs, wg / p.q.nslabs, wave, lane, g4q);
             C4::prefetch(pool, g4q);
+            C4::prefetch_l2(g4q, wave, g4q.quarter, l2_scratch, p.l2_units);
             pre4 = true;
         }
     };
-    if (norm_wg) {
+    if (norm2_wg) {
         tail_wait(p.sync, 3, target, p.spin_limit, wave, lane);
-        tail_norm_row<E>(p, p.down.S, norm_row, p.norm2_w, smem, tid);
+        TAIL_STAMP(11);
+        norm_rows(p.down.S, p.n2_rows, G - n2_wgs, p.norm2_w);
         tail_arrive(p.sync, 4);
+        TAIL_STAMP(12);
         prefetch_q();
     } else {
         tail_arrive(p.sync, 4);
@@ -969,6 +1040,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
     // ---------------- P4: the next layer's q|k|v + RoPE ----------------
     if (has_q) {
         tail_wait(p.sync, 4, target, p.spin_limit, wave, lane);
+        TAIL_STAMP(13);
         const TailW& w = p.q;
         const int n_items = w.nslabs * w.S;
         constexpr int TILE_F = MT * 4 * 64;
@@ -1080,6 +1152,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
             __syncthreads();
         }
     }
+    TAIL_STAMP(14);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA request of this wave outlives it (a no-op here: the main loops waited)
     // the generation moves on: every workgroup has read it (this workgroup's waits above needed all G arrivals at C2)
     if (wg == 0 && tid == 0) __hip_atomic_store(p.sync, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1327,8 +1401,12 @@ static int tail_plan(const ls_layer_tail_desc* d, TailPlan& tp) {
     off += (size_t)maxS * TAIL_MP * d->hidden * 4;
     tp.off_qpart = off;
     off += tp.has_q ? tp.q.part_bytes : 0;
+#ifdef LS_TAIL_PROF
+    off = (off + 255) & ~(size_t)255;
+    off += (size_t)tp.G * 16 * 8;                            // the stamps are the LAST G * 128 bytes of the workspace
+#endif
     tp.total = off;
-    tp.lds = (size_t)16 * 4 * 5 * 64 * 4 + 16;               // as the MT = 5 stand-alone launch: 4 waves x 4 tiles x 5 accumulators + the flag
+    tp.lds = (size_t)16 * 4 * 5 * 64 * 4 + 16 + 1024;        // as the MT = 5 stand-alone launch (4 waves x 4 tiles x 5 accumulators + the flag) + the DMA scratch slot
     return LS_OK;
 }
 
@@ -1495,7 +1573,36 @@ int ls_layer_tail_fwd(const ls_layer_tail_desc* d, void* workspace, size_t works
     if (tp.has_q) tail_fill(tp.q, d->w_qkv, d->b_qkv, d->n_qkv, d->n_qkv_seg, d->hidden, k.q);
     k.sync = reinterpret_cast<unsigned*>(ws);
     k.spin_limit = 1u << 19;
-    k.flag_off = (int)tp.lds - 16;
+    k.flag_off = (int)tp.lds - 16 - 1024;
+    k.l2_scratch_off = (int)tp.lds - 1024;
+    {
+        // Seam-time L2 prefetch: measured NEGATIVE (profiles/r4_tail_timeline_l2_*.json: 4 units = 32 KB per wave make the
+        // norm phases -- the critical path of a seam -- twice as long, 5.5 -> 11 us: their partial reads queue behind 25 MB of
+        // other workgroups' prefetch; the launch goes 126 -> 128.5 us, with 8 units 137).  Off; LS_TAIL_L2_UNITS re-enables it.
+        static int l2u = -1;
+        if (l2u < 0) {
+            const char* e = getenv("LS_TAIL_L2_UNITS");
+            l2u = e ? atoi(e) : 0;
+            if (l2u < 0 || l2u > 16) l2u = 0;
+        }
+        k.l2_units = l2u;
+        // rows per norm workgroup: the smallest of 1, 2, 4 that fits the phase into the workgroups WITHOUT an item of the
+        // projection behind it (a norm workgroup starts that projection late: no requests in flight while it normalises)
+        auto pick_rows = [&](int items, const char* env) {
+            const char* e = getenv(env);
+            if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) return atoi(e);
+            const int idle = tp.G - items;
+            for (int r = 1; r <= 4; r *= 2)
+                if ((d->M + r - 1) / r <= idle) return r;
+            return 1;
+        };
+        k.n1_rows = pick_rows(tp.gu.nslabs * tp.gu.S, "LS_TAIL_N1_ROWS");
+        k.n2_rows = tp.has_q ? pick_rows(tp.q.nslabs * tp.q.S, "LS_TAIL_N2_ROWS") : 1;
+    }
+    k.prof = nullptr;
+#ifdef LS_TAIL_PROF
+    k.prof = reinterpret_cast<unsigned long long*>(ws + tp.total - (size_t)tp.G * 16 * 8);
+#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
     rc = d->dtype == LS_F16 ? tail_launch<ElemF16>(k, tp, s) : tail_launch<ElemBF16>(k, tp, s);
