@@ -345,9 +345,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true", help="skip the vanilla-decode denominator (profiling runs)")
     ap.add_argument("--no-graphs", action="store_true", help="issue every round launch by launch (no HIP-graph replay)")
-    ap.add_argument("--no-layer-tail", action="store_true",
-                    help="A/B: the verification pass layer by layer (eight launches between two attention calls) instead of the "
-                         "persistent layer-tail launch (ops.layer_tail, round 4)")
+    ap.add_argument("--layer-tail", action="store_true",
+                    help="A/B: the verification pass with ONE persistent launch between two attention calls (ops.layer_tail, round 4: "
+                         "bit-identical, measured not faster, off by default) instead of the eight launches")
+    ap.add_argument("--no-layer-tail", action="store_true", help="(the default since the round-4 measurement)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no event-bracketed rounds (no roofline objects): every round is a graph replay")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -373,9 +374,8 @@ def main():
                          "and prefix -- configs[3]'s chain-vs-tree A/B (inference_long-bench.py --method seq | tree).  The line of a seq "
                          "run carries no roofline objects (its target pass is a 5-row decode pass, not the 74-row verification)")
     args = ap.parse_args()
-    if args.no_layer_tail:
-        from longspec_amd import ops as _o
-        _o.LAYER_TAIL = False
+    from longspec_amd import ops as _o
+    _o.LAYER_TAIL = bool(args.layer_tail and not args.no_layer_tail)
     if args.config is not None:
         preset = BASELINE_CONFIGS[args.config]
         args.model = preset["model"]

@@ -872,9 +872,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK
     const bool norm1_wg = wg >= G - n1_wgs, norm2_wg = wg >= G - n2_wgs;
     auto norm_rows = [&](int S, int rows_per_wg, int first_wg, const char* nw) {
         const int row0 = (wg - first_wg) * rows_per_wg;
-        if (rows_per_wg == 1) tail_norm_row<E, 256>(p, S, row0, nw, smem, tid);
-        else if (rows_per_wg == 2) tail_norm_row<E, 128>(p, S, row0, nw, smem, tid);
-        else tail_norm_row<E, 64>(p, S, row0, nw, smem, tid);
+        tail_norm_row<E, 256>(p, S, row0, nw, smem, tid);
     };
     typedef __attribute__((address_space(3))) char lds_char_t;
     const unsigned l2_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)(smem + p.l2_scratch_off));
@@ -1588,16 +1586,11 @@ int ls_layer_tail_fwd(const ls_layer_tail_desc* d, void* workspace, size_t works
         k.l2_units = l2u;
         // rows per norm workgroup: the smallest of 1, 2, 4 that fits the phase into the workgroups WITHOUT an item of the
         // projection behind it (a norm workgroup starts that projection late: no requests in flight while it normalises)
-        auto pick_rows = [&](int items, const char* env) {
-            const char* e = getenv(env);
-            if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) return atoi(e);
-            const int idle = tp.G - items;
-            for (int r = 1; r <= 4; r *= 2)
-                if ((d->M + r - 1) / r <= idle) return r;
-            return 1;
-        };
-        k.n1_rows = pick_rows(tp.gu.nslabs * tp.gu.S, "LS_TAIL_N1_ROWS");
-        k.n2_rows = tp.has_q ? pick_rows(tp.q.nslabs * tp.q.S, "LS_TAIL_N2_ROWS") : 1;
+        // One row per norm workgroup.  Two or four rows side by side (so that the phase fits into the workgroups without an
+        // item of the projection behind it) were measured: the phase is bound by what ONE compute unit pulls of the
+        // write-through partials -- 5.5 us for one row, 10 for two, 19 for four (profiles/r4_tail_timeline_rows_*.json).
+        k.n1_rows = 1;
+        k.n2_rows = 1;
     }
     k.prof = nullptr;
 #ifdef LS_TAIL_PROF

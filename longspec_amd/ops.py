@@ -399,7 +399,11 @@ def mlp_gate_up(x: torch.Tensor, gate_up: PackedWeight, n_splits: int = 0, timin
 
 
 # ---- the persistent layer tail (one launch between two attention calls of a verification pass) -------------------------
-LAYER_TAIL = True            # tools/ab_round.py ops.LAYER_TAIL flips it; the models ask layer_tail_supported()
+# Round-4 measurement (profiles/r4_tail_*.json): the persistent launch is bit-identical to the eight launches it
+# replaces and NOT faster -- 126-131 us per layer against ~128: each of its two norm seams costs ~12 us (two counter hops of
+# 2-3 us and a 5.5 us norm phase bound by one CU's pull of the write-through partials) where the launch chain pays ~15, and the
+# projections inside it stream no faster than the stand-alone launches.  Off by default; bench.py --layer-tail measures it.
+LAYER_TAIL = False
 _tail_ws = {}                # device index -> the DEDICATED, zero-initialised workspace (it carries the launch generation)
 _tail_need = {}
 _tail_timing = None

@@ -119,3 +119,37 @@ def test_layer_tail_under_load_and_replayed_from_a_graph():
         assert torch.equal(cap[0], want[0]) and torch.equal(cap[1], want[1])
         assert all(torch.equal(a, b) for a, b in zip(cap[2], want[2]))
     ops.layer_tail_check()
+
+
+@pytest.mark.parametrize("name", ["mixed", "qwen_g7", "gqa_mixed"])
+def test_generation_with_the_layer_tail_matches_the_reference(name):
+    """The model path behind ops.LAYER_TAIL (LlamaModel._forward_tail: one persistent launch between two attention calls of the
+    74-row verification pass) reproduces the reference's golden token ids, eagerly and replayed from HIP graphs."""
+    import cases
+    from longspec_amd import ops
+    import test_gpu_generate as G
+    run = [r for r in cases.generate_runs() if r["name"] == name][0]
+    old = ops.LAYER_TAIL
+    ops.LAYER_TAIL = True
+    try:
+        for graph_after in (None, 0):
+            m = G.build(run)
+            if graph_after is not None:
+                m.GRAPH_AFTER = graph_after
+            ids = run["prompt"].cuda()
+            pl = torch.tensor([run["prompt_len"]], device="cuda")
+            calls = []
+            orig = ops.layer_tail
+            ops.layer_tail = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"],
+                                                                 eos_id=run["eos_id"])
+            finally:
+                ops.layer_tail = orig
+            assert torch.equal(t_out.cpu(), run["tree_out"])
+            assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
+            if len(run["tree_shape"]) == 5 and sum(run["tree_shape"]) == 68:
+                assert calls, "the verification pass did not take the fused path"
+        ops.layer_tail_check()
+    finally:
+        ops.LAYER_TAIL = old
