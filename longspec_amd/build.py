@@ -73,10 +73,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if verbose:
                 print("[longspec_amd.build]", " ".join(cmd), flush=True)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-            _write_usage(r.stderr, usage)
             if r.returncode != 0:
                 sys.stderr.write(r.stderr)
                 raise subprocess.CalledProcessError(r.returncode, cmd)
+            _write_usage(r.stderr, usage)
+            # the compiler's own warnings reach the user; the resource-usage remarks (thousands of lines) go to the json
+            noise = ("-Rpass-analysis=kernel-resource-usage", "remark:")
+            for line in r.stderr.splitlines():
+                if line.strip() and not any(n in line for n in noise) and "warning" in line:
+                    sys.stderr.write(line + "\n")
         objs.append(obj)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]

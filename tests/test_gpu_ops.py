@@ -589,8 +589,9 @@ def test_mutant_is_caught():
     zeroes the weights of ONE 32-key block -- block 5 of split 3 of kv head 1 -- out of 4096) has to FAIL it.  The mutant is
     built by __graft_entry__.build() / tools/build_variant.py; it is never the library the product loads."""
     import subprocess
-    mutant = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "longspec_amd", "_lib", "liblongspec_hip_mutant.so")
-    assert os.path.exists(mutant), "build it: python tools/build_variant.py mutant -DLS_MUTATE_SKIP_BLOCK"
+    from longspec_amd.build import build_variant
+    mutant = build_variant("mutant", ["-DLS_MUTATE_SKIP_BLOCK"], verbose=False)     # (a no-op when the in-tree one is up to date)
+    assert os.path.exists(mutant)
     env = dict(os.environ, LONGSPEC_HIP_LIB=mutant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_full_size_verify_attention_vs_oracle and 131072-False"], env=env, capture_output=True, text=True, timeout=600)
