@@ -810,7 +810,8 @@ constexpr int WS_NV = WS_LA + 3;                 // V ring stages: ... to step b
 constexpr int WS_BLK_B = 32 * ROWB;              // 8 KB: 32 keys of K (or V)
 constexpr int WS_PBUF_B = 4 * WS_QT * 1024;      // one P buffer: 4 pairs x 5 row tiles x (64 lanes x 16 B)
 constexpr int WS_RING_B = (WS_NK + WS_NV) * WS_BLK_B;
-constexpr int WS_LDS = WS_RING_B + 2 * WS_PBUF_B + 4 * 80 * 4 + 16;
+constexpr int WS_SAT_WORDS = 64;                 // bitmap of the split's 32-key blocks that held a saturated numerator (<= 2048 blocks)
+constexpr int WS_LDS = WS_RING_B + 2 * WS_PBUF_B + 4 * 80 * 4 + 16 + WS_SAT_WORDS * 4 + 4 * 80 * 4;
 constexpr int WS_NEW_CAP = WS_RING_B / (2 * ROWB);   // keys the new-block workgroup can hold in the same LDS
 
 // S^T of one 32-key block with ALL 8 K fragments fetched from LDS before the first MFMA (one exposed LDS latency per
@@ -862,6 +863,20 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
     char* pbuf = smem + WS_RING_B;
     float* s_inv = reinterpret_cast<float*>(pbuf + 2 * WS_PBUF_B);
     int* redo_flag = reinterpret_cast<int*>(s_inv + 4 * 80);
+    unsigned* sat_bits = reinterpret_cast<unsigned*>(redo_flag + 4);
+    float* s_fac = reinterpret_cast<float*>(sat_bits + WS_SAT_WORDS);
+    // fp16 only: a soft-max numerator that leaves the fp16 range (a key more than 16 + WS_HEADROOM octaves above the split's
+    // reference: a retrieval spike, a sink outside the first 64 keys) converts to 65504 instead of +inf (MODE.FP16_OVFL in the S
+    // waves) -- the accumulators stay finite --, the O wave notes its block in `sat_bits` (the row sums jump by >= 65504), and
+    // behind the loop the noted blocks are visited once more
+    // (`correct_block`): the S wave recomputes their scores, raises the rows' reference to the largest of them and hands the O
+    // wave the true numerators minus the 65504 stand-ins, after a rescale of the rows' accumulators.  Round 3 redid the WHOLE
+    // split twice (a QK-only pass for the true maxima, then the loop again: 2.7x for that workgroup, and the launch waits for
+    // it); now the price is ~3 steps per noted block.  bf16 numerators (exponent range of fp32) cannot saturate.
+    // (QT == 5 only: the three-tile instantiation -- fp16 row blocks of 21..24 tiles, none among BASELINE's models, QwQ is bf16 --
+    // does not fit the extra state into 256 registers and keeps round 3's redo.)
+    constexpr bool SAT_FIX = std::is_same<E, ElemF16>::value && QT == WS_QT;
+    if (SAT_FIX && tid < WS_SAT_WORDS) sat_bits[tid] = 0u;      // (visible behind pass_head's barrier)
 
     // The split's key range in 32-key blocks: ceil(B / n) blocks per split, the last split takes what is left.  (Until round 3
     // the splits were cut at 64-key TILE boundaries, ceil(tiles / n) tiles each: at 16k that is 18 blocks for 28 of the 31 splits,
@@ -934,6 +949,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
     const unsigned p_base = smem_a + WS_RING_B + pair * QT * 1024 + lane * 16;
 
     if constexpr (S_ROLE) {
+        // MODE.FP16_OVFL = 1 in the S waves: a numerator beyond the fp16 range converts to 65504 instead of +inf (true
+        // infinities stay), at no instruction -- the saturation "clamp" of the scheme described at `sat_bits`
+        if constexpr (SAT_FIX) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
         typename E::V8 qf[QT][4];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -1120,6 +1138,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         __syncthreads();                                   // (the O waves raise the flag in between)
         if (*redo_flag) {
             if (tid == 0) atomicAdd(&g_attn_redo_count, 1u);
+            // (a split redone with its true row maxima -- a numerator beyond fp32, > 88 nats above the reference -- needs no
+            // correction: the notes of pass 0 are void.  A flag carried across the two passes cost 688 bytes of scratch.)
+            if (SAT_FIX && tid < WS_SAT_WORDS) sat_bits[tid] = 0u;
             __syncthreads();
             run_pass(1);
             run_pass(2);
@@ -1133,10 +1154,62 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             reinterpret_cast<unsigned long long*>(p.new_o)[lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
                                                                    prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
 #endif
+        float mcur[QT];                                    // the rows' reference after the corrections below (= mref without)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) mcur[qt] = mref[qt];
+        if constexpr (SAT_FIX) {
+            typedef __attribute__((address_space(3))) typename E::V8 lds_v8c;
+            const int nwords = min(WS_SAT_WORDS, (nblocks + 31) >> 5);
+            for (int w = 0; w < nwords; ++w) {
+                unsigned bits = __builtin_amdgcn_readfirstlane(sat_bits[w]);
+                while (bits) {
+                    const int b = w * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    // ---- correct_block(b), S role: barriers B1 (block landed), B2 (P and the row factors are in LDS), B3 (consumed)
+                    dma(b);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    f32x4 sc[2][QT];
+                    qk_block<E, QT>(sc, qf, tb, k_addr(b));
+                    mask_tail(sc, b);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const float m0c = mref[qt] * c;
+                        bool sat[8];
+                        float smax = -INFINITY;
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                // exactly the loop's numerator: it was clamped <=> its fp32 value rounds beyond 65504
+                                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][qt][e], c, -m0c));
+                                sat[kt * 4 + e] = p0 >= 65520.0f;
+                                if (sat[kt * 4 + e]) smax = fmaxf(smax, sc[kt][qt][e]);
+                            }
+                        smax = wave_xor_max_16_32(smax);
+                        const float m_new = fmaxf(mcur[qt], smax);
+                        const float fac = m_new == mcur[qt] ? 1.0f : __builtin_amdgcn_exp2f((mcur[qt] - m_new) * c);
+                        const float stand = 65504.0f * __builtin_amdgcn_exp2f((mref[qt] - m_new) * c);     // what the loop added per saturated key, in the new scale
+                        typename E::V8 pf;
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                pf[kt * 4 + e] = E::from_f32(sat[kt * 4 + e] ? __builtin_amdgcn_exp2f((sc[kt][qt][e] - m_new) * c) - stand : 0.0f);
+                        *(lds_v8c*)(uintptr_t)(p_base + qt * 1024) = pf;
+                        if (g4 == 0) s_fac[pair * 80 + qt * 16 + l15] = fac;
+                        mcur[qt] = m_new;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
         // the reference of every row, for the O wave's log-normaliser lse = m*scale + ln(l)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
-            if (g4 == 0) s_inv[pair * 80 + qt * 16 + l15] = mref[qt] * p.scale;
+            if (g4 == 0) s_inv[pair * 80 + qt * 16 + l15] = mcur[qt] * p.scale;
         __syncthreads();
     } else {
         f32x4 acc[8][QT];
@@ -1144,7 +1217,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         typename E::V8 ones;                       // A operand of that tile: row 0 (lanes with l15 == 0) = 1 for every key
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = E::from_f32(l15 == 0 ? 1.f : 0.f);
+        float sat_prev = 0.f;                      // the five rows' total of the previous step (saturation watch)
         auto run_pass = [&](int mode) {
+            sat_prev = 0.f;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1185,6 +1260,18 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
+                    if constexpr (SAT_FIX) {
+                        // a saturated numerator adds >= 65504 to its row's sum: one comparison of the five rows' running total
+                        // per step (7 vector instructions; any VALU work in this wave comes out of the SIMD the pair shares --
+                        // clamping and scanning the numerators here, 48 instructions per step, cost 12 % of the kernel).
+                        // A step whose ordinary numerators add up to as much is noted too: its correction finds nothing to do.
+                        float tot = lacc[0][0];
+#pragma unroll
+                        for (int qt = 1; qt < QT; ++qt) tot += lacc[qt][0];
+                        if (__any(tot - sat_prev >= 65504.0f) && lane == 0)
+                            __hip_atomic_fetch_or(sat_bits + (jj >> 5), 1u << (jj & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        sat_prev = tot;
+                    }
                 }
 #if LS_WS_O_DMA_LATE
                 // The O wave requests its two pieces of block j+1+LA BEHIND its MFMAs (their slots have been free since step
@@ -1224,6 +1311,50 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             reinterpret_cast<unsigned long long*>(p.new_o)[8 + lane] = prof[0] * (lane == 0) + prof[1] * (lane == 1) + prof[2] * (lane == 2) +
                                                                        prof[3] * (lane == 3) + prof[4] * (lane == 4) + (unsigned long long)nblocks * (lane == 5);
 #endif
+        if constexpr (SAT_FIX) {
+            const int nwords = min(WS_SAT_WORDS, (nblocks + 31) >> 5);
+            for (int w = 0; w < nwords; ++w) {
+                unsigned bits = __builtin_amdgcn_readfirstlane(sat_bits[w]);
+                while (bits) {
+                    const int b = w * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    // ---- correct_block(b), O role
+                    dma(b);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();          // B2: the S wave's numerators and row factors
+                    typename E::V8 pf[QT];
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const float fac = s_fac[pair * 80 + qt * 16 + l15];
+                        pf[qt] = lds_read16<typename E::V8>(p_base + qt * 1024);
+                        lacc[qt] *= fac;
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) acc[dt][qt] *= fac;
+                    }
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4c;
+                    int vx = tb.vx;
+                    asm volatile("" : "+v"(vx));
+                    const unsigned vb = v_addr(b) + tb.vb;
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        union {
+                            struct { s16x4 a, b; } s;
+                            typename E::V8 v;
+                        } vf;
+                        const unsigned va = vb + ((dt ^ vx) << 5);
+                        vf.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(uintptr_t)va);
+                        vf.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(uintptr_t)(va + 16 * ROWB));
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf.v, pf[qt], acc[dt][qt]);
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();          // B3
+                }
+            }
+        }
         __syncthreads();                           // the pair's m*scale is in LDS
         WS_MARK(5);                                // ready to write the partial
 #pragma unroll
