@@ -41,10 +41,21 @@ def load_config(path: str) -> SimpleNamespace:
 
 
 def _snapshot_complete(path: str) -> bool:
+    """Tensors present, and ALL of them: an index that names absent shards is incomplete, and so is a directory of
+    ``model-0000i-of-0000N`` shards (no index: an interrupted download) that does not hold all N."""
+    import re
     try:
-        return bool(checkpoint_files(path))
+        files = checkpoint_files(path)
     except FileNotFoundError:                    # an index that names absent shards
         return False
+    if not files:
+        return False
+    shards = {}
+    for f in files:
+        m = re.search(r"-(\d+)-of-(\d+)\.(safetensors|bin)$", os.path.basename(f))
+        if m:
+            shards.setdefault(int(m.group(2)), set()).add(int(m.group(1)))
+    return all(len(have) == total for total, have in shards.items())
 
 
 def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
@@ -67,6 +78,8 @@ def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
         # its index names -- is complete; anything else goes on to the networked pass, which fetches what is missing.
         if _snapshot_complete(cached):
             return cached
+        if not need_tensors and os.path.exists(os.path.join(cached, "config.json")):
+            return cached                        # load_config: the cached config.json is all it reads -- no multi-GB download for it
     except Exception:
         pass
     try:

@@ -184,6 +184,28 @@ __device__ __forceinline__ void pv_block(WaveAcc<E, QT>& w, const typename E::V8
 //                 key scoring e^11 above everything seen so far); the largest p is tracked in
 //                 `pmax` and the caller re-runs the split with SAFE = true if it ever gets near the
 //                 fp16 range.  (lse = m*scale + ln(l) holds for any reference m.)
+// Round 4: the fixed-reference form raises its reference LAZILY.  The eight numerators of a lane are summed in fp32 before they
+// are rounded to 16 bits; a sum beyond 2^12 (a key 8+ nats above everything the split has seen: a retrieval spike, a heavy
+// tail) triggers, wave-uniformly and in the same block, the textbook step -- row maximum, rescale of O and l, new reference --
+// and the block's numerators are recomputed against it.  Until round 3 such a block only raised a flag and the whole split
+// ran again in textbook form (1.75-2x per call on N(0, 4^2) logits or a few +14-nat keys: profiles/r4_redo_general_kernel.jsonl);
+// a call whose scores stay within 8 nats of their running reference executes exactly the instructions it did.
+constexpr float LAZY_RAISE_SUM = 4096.f;
+template <typename E, int QT>
+__device__ __forceinline__ void raise_reference(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], int qt, float c) {
+    float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                     fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+    mx = wave_xor_max_16_32(mx);
+    const float m_new = fmaxf(w.m[qt], mx);
+    if (m_new > w.m[qt]) {                          // (per lane = per row: rows below their reference keep every bit)
+        const float alpha = __builtin_amdgcn_exp2f((w.m[qt] - m_new) * c);
+        w.l[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) w.acc[dt][qt] *= alpha;
+        w.m[qt] = m_new;
+    }
+}
+
 template <typename E, int QT, bool SAFE>
 __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)[2][QT], float c, const LaneTbl& tb,
                                              unsigned vbase, float& pmax) {
@@ -208,17 +230,31 @@ __device__ __forceinline__ void online_block(WaveAcc<E, QT>& w, const f32x4 (&s)
         } else {
             mc = w.m[qt] * c;
         }
+        float pe[8];
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
-                ps += pe;
-                pf[qt][kt * 4 + e] = E::from_f32(pe);
+                pe[kt * 4 + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                ps += pe[kt * 4 + e];
             }
+        if (!SAFE && __any(!(ps <= LAZY_RAISE_SUM))) {      // rare (also catches a non-finite sum)
+            raise_reference<E, QT>(w, s, qt, c);
+            mc = w.m[qt] * c;
+            ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pe[kt * 4 + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                    ps += pe[kt * 4 + e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[qt][e] = E::from_f32(pe[e]);
         w.l[qt] += ps;
-        if (!SAFE) pmax = fmaxf(pmax, ps);   // sum of 8 probabilities: a conservative stand-in for their max
+        if (!SAFE) pmax = fmaxf(pmax, ps);   // (stays far below the redo threshold now: kept as the safety net it was)
     }
     pv_block<E, QT>(w, pf, tb, vbase);
 }
@@ -231,18 +267,32 @@ __device__ __forceinline__ void softmax_fast(WaveAcc<E, QT>& w, const f32x4 (&s)
                                              float& pmax) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const float mc = w.m[qt] * c;
+        float mc = w.m[qt] * c;
+        float pe[8];
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
-                ps += pe;
-                pf[qt][kt * 4 + e] = E::from_f32(pe);
+                pe[kt * 4 + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                ps += pe[kt * 4 + e];
             }
+        if (__any(!(ps <= LAZY_RAISE_SUM))) {       // rare: see raise_reference (the caller's P.V of the PREVIOUS block was issued first)
+            raise_reference<E, QT>(w, s, qt, c);
+            mc = w.m[qt] * c;
+            ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pe[kt * 4 + e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][e], c, -mc));
+                    ps += pe[kt * 4 + e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[qt][e] = E::from_f32(pe[e]);
         w.l[qt] += ps;
-        pmax = fmaxf(pmax, ps);        // sum of 8 probabilities: a conservative stand-in for their max
+        pmax = fmaxf(pmax, ps);
     }
 }
 
@@ -1796,7 +1846,16 @@ int pick_splits(const ls_attn_desc* d, const Cfg& c) {
     // all launch long: 32 splits of a 131072-row prefix (4096 rows each) take 116 us per call, 31 splits 106.5
     // (tools/sweep_cross_attn_128k.py).  Calls with a new-key block have an odd split count already (one CU per kv head
     // goes to that block); the others give up a split for an odd stride.
-    while (s > 1 && tiles > s && (((tiles + s - 1) / s) * tile) % 512 == 0) --s;
+    // The stride is computed the way the dispatched kernel cuts its splits (the warp-specialised kernel: ceil(blocks / s)
+    // 32-key blocks from the hinted length; the general one: ceil(tiles / s) tiles), only for calls WITHOUT a new-key block,
+    // and never below half the target (tiles = 16, s = 2 used to collapse to one split).
+    if (d->new_mode == LS_NEW_NONE) {
+        const int unit = c.ws ? 32 : tile;
+        const int units = (span + unit - 1) / unit;
+        int t = s;
+        while (t > 1 && units > t && (((units + t - 1) / t) * unit) % 512 == 0) --t;
+        if (2 * t >= s) s = t;
+    }
     return s;
 }
 

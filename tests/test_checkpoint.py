@@ -75,3 +75,11 @@ def test_partial_hub_snapshot_falls_through_to_the_download(tmp_path, monkeypatc
     json.dump({"weight_map": {"w": "model-00001-of-00002.safetensors"}}, open(partial / "model.safetensors.index.json", "w"))
     monkeypatch.setattr(huggingface_hub, "snapshot_download", fake)
     assert checkpoint.resolve_path("org/some-model") == str(full)
+    # ... and so is a directory of numbered shards without an index that lacks some of them (an interrupted download)
+    os.remove(partial / "model.safetensors.index.json")
+    save_file({"w": torch.ones(2)}, str(partial / "model-00001-of-00003.safetensors"))
+    calls.clear()
+    assert checkpoint.resolve_path("org/some-model") == str(full) and calls == [True, False]
+    # load_config on a config-only snapshot reads the cached config.json WITHOUT the networked pass
+    calls.clear()
+    assert checkpoint.load_config("org/some-model").hidden_size == 256 and calls == [True]
