@@ -846,9 +846,6 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
 // true row maxima, then the same loop with those.  K and V stream through separate rings of 32-key blocks
 // (global_load_lds from all 8 waves, one K and one V piece per wave and step): block b is issued LA steps
 // before its K is multiplied (step b-1) and its V slot is released two steps later.
-#ifndef LS_WS_O_DMA_LATE
-#define LS_WS_O_DMA_LATE 0
-#endif
 #ifndef LS_WS_HEADROOM
 #define LS_WS_HEADROOM 4
 #endif
@@ -1281,9 +1278,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll 1
             for (int j = 0; j <= nblocks; ++j) {
                 WS_T0();
-#if !LS_WS_O_DMA_LATE
                 step_head(j);
-#endif
                 WS_TS(0);
                 if (mode != 1 && j >= 1) {
                     const int jj = j - 1;
@@ -1323,13 +1318,6 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         sat_prev = tot;
                     }
                 }
-#if LS_WS_O_DMA_LATE
-                // The O wave requests its two pieces of block j+1+LA BEHIND its MFMAs (their slots have been free since step
-                // j-1): right behind the barrier all 8 waves of the workgroup would push 16 KB through the CU's address path at
-                // once and sit in the issue stall together (r3 timeline: 226 / 117 ns per step in the S / O wave); now the S waves
-                // stall while their partners multiply, and the O waves while their partners run the soft-max.
-                step_head(j);
-#endif
                 WS_TS(1);
                 // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
                 if (j + 2 + WS_LA <= nblocks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1)) : "memory");
