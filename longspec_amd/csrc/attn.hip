@@ -1637,7 +1637,10 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         __syncthreads();
         if (tid == 0) {
             unsigned int* ctr = &p.x_ctl->arrive_all;
-            const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            // RELAXED: the record travels as write-through stores that are acknowledged (vmcnt(0)) in front of the barrier above, so
+            // the count has nothing to release -- an acq_rel count is `buffer_wbl2 sc1` + `buffer_inv sc1` in each of the 320
+            // workgroups (round 4 A/B at 16k rows per rank: 26.3 -> 23.7 us per exchange, profiles/r4_xchg_arrive_relaxed.json)
+            const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (prev == gridDim.x * gridDim.y * gridDim.z - 1) {       // the whole record has landed everywhere: raise the flags
                 __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int dst = 0; dst < p.x_world; ++dst) xchg_raise_flag(p.x_peers[dst], parity, p.x_rank, epoch);

@@ -198,7 +198,12 @@ __device__ __forceinline__ void xchg_wait_flag(const char* box, XCtl* ctl, int p
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(box) + parity * XCHG_MAX_WORLD + src;
     unsigned spins = 0;
     if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // latched: never wait twice
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    // RELAXED polls and no acquire behind them: the mailbox is UNCACHED device memory (ls_xchg_create), so the record is read
+    // from HBM whatever the caches hold, the reads are issued behind this loop (and behind the caller's barrier), and everything
+    // else the merge reads was written by earlier kernels of this stream.  An acquiring poll is `buffer_inv sc0 sc1` per poll in
+    // every workgroup -- it throws the tree part, written by the launch in front, out of the L2 (round 4: 23.7 -> 22.0 us per
+    // exchange at 16k rows per rank, profiles/r4_xchg_arrive_relaxed.json).
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
         __builtin_amdgcn_s_sleep(32);
         if (++spins > ctl->spin_limit) {
             __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -37,11 +37,12 @@ __global__ __launch_bounds__(XCHG_THREADS) void xchg_push_kernel(const float* __
     xchg_stores_done();                            // this thread's peer stores are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(&ctl->arrive_push[dst], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed counts: the stores above are write-through and acknowledged -- see attn.hip, attn_finish_kernel)
+        const unsigned prev = __hip_atomic_fetch_add(&ctl->arrive_push[dst], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {               // the record is complete in the peer's mailbox
             __hip_atomic_store(&ctl->arrive_push[dst], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             xchg_raise_flag(box, parity, rank, epoch);
-            if (__hip_atomic_fetch_add(&ctl->arrive_all, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) {
+            if (__hip_atomic_fetch_add(&ctl->arrive_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1) {
                 __hip_atomic_store(&ctl->arrive_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&ctl->epoch, epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // every flag of this epoch is up
             }
