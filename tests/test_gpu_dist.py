@@ -180,3 +180,52 @@ def test_peer_exchange_two_processes_one_gpu():
     for rank, ok, bad, done, timed_out in res:
         assert ok and bad == 0 and not timed_out, (rank, ok, bad, timed_out)
         assert done == 3 + 60 + 3 + 15, "self-check + eager + warm-up + 5 replays of 3"
+
+
+def _silent_peer_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import time
+    from longspec_amd import _C
+    from longspec_amd.dist import PeerExchange
+    px = PeerExchange(rank, world, 4096, dev)
+    ok = px.self_check()
+    _C.check(px.lib.ls_xchg_set_timeout(px._x, 0.2), "ls_xchg_set_timeout")
+    took, timed_out, second = 0.0, False, 0.0
+    if rank == 0:                                    # rank 1 never joins this exchange
+        send = torch.ones(4096, dtype=torch.float32, device=dev)
+        recv = torch.zeros((world, 4096), dtype=torch.float32, device=dev)
+        t0 = time.time()
+        px.all_gather(send, recv)
+        torch.cuda.synchronize()
+        took = time.time() - t0
+        timed_out = px.status()[1]
+        t0 = time.time()
+        px.all_gather(send, recv)                    # latched: a second wait returns at once
+        torch.cuda.synchronize()
+        second = time.time() - t0
+    q.put((rank, ok, took, timed_out, second))
+    dist.barrier()                                   # rank 1 keeps its mailbox mapped until rank 0 is through
+    px.close()
+    dist.destroy_process_group()
+
+
+def test_a_wait_on_a_silent_peer_gives_up_and_latches():
+    """Failure detection of the peer exchange: a rank whose peer never pushes does not hang the GPU -- its wait polls for the
+    configured time, latches `timed_out` (ls_xchg_status) and every later wait returns immediately."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_silent_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(world)))
+    [p.join(timeout=60) for p in procs]
+    ok, took, timed_out, second = res[0]
+    assert ok and res[1][0]
+    assert timed_out, "the wait must give up"
+    assert took < 20.0, f"gave up only after {took:.1f} s"           # (0.2 s of polls; generous: a poll's period is approximate)
+    assert second < 2.0, f"a latched exchange waited again ({second:.1f} s)"
