@@ -1265,8 +1265,13 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = E::from_f32(l15 == 0 ? 1.f : 0.f);
         float sat_prev = 0.f;                      // the five rows' total of the previous step (saturation watch)
+        // The bitmap covers WS_SAT_WORDS * 32 = 2048 blocks (65536 keys) of a split.  A saturated numerator in a LATER block (a
+        // forced n_splits = 1 or a batched prompt call over > 64k keys per split) cannot be noted -- and since FP16_OVFL clamps
+        // instead of producing inf, nothing else would catch it: it takes the true-maxima redo instead.
+        bool sat_far = false;                      // wave-uniform
         auto run_pass = [&](int mode) {
             sat_prev = 0.f;
+            sat_far = false;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1313,8 +1318,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         float tot = lacc[0][0];
 #pragma unroll
                         for (int qt = 1; qt < QT; ++qt) tot += lacc[qt][0];
-                        if (__any(tot - sat_prev >= 65504.0f) && lane == 0)
-                            __hip_atomic_fetch_or(sat_bits + (jj >> 5), 1u << (jj & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__any(tot - sat_prev >= 65504.0f)) {
+                            if (jj >= WS_SAT_WORDS * 32) sat_far = true;
+                            else if (lane == 0)
+                                __hip_atomic_fetch_or(sat_bits + (jj >> 5), 1u << (jj & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                         sat_prev = tot;
                     }
                 }
@@ -1336,7 +1344,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             bool bad = false;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) bad |= !(fabsf(lacc[qt][0]) <= 3.0e38f);
-            if (__any(bad && g4 == 0) && lane == 0) *redo_flag = 1;
+            if ((__any(bad && g4 == 0) || sat_far) && lane == 0) *redo_flag = 1;
         }
         __syncthreads();
         if (*redo_flag) {

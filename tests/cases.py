@@ -127,10 +127,14 @@ def rope_cases():
 
 
 def generate_runs(family="llama"):
-    """family: "llama", "qwen2", or "qwen2_bf16" (the Qwen2 twin in bfloat16, as inference_qwq.py runs QwQ)."""
-    dtype = torch.bfloat16 if family == "qwen2_bf16" else torch.float16
-    g = load_golden({"llama": "generate", "qwen2": "generate_qwen2", "qwen2_bf16": "generate_qwen2_bf16"}[family])
-    family = "llama" if family == "llama" else "qwen2"
+    """family: "llama", "qwen2", or "qwen2_bf16" (the Qwen2 twin in bfloat16, as inference_qwq.py runs QwQ); with the
+    suffix "_long" the runs of the regime every BASELINE configuration is in (prompt >= 700 tokens: the draft's 512-row
+    window truncates from round 1; >= 64 rounds; three seeds per weight kind -- make_golden.py::gen_generate_long)."""
+    dtype = torch.bfloat16 if family.startswith("qwen2_bf16") else torch.float16
+    g = load_golden({"llama": "generate", "qwen2": "generate_qwen2", "qwen2_bf16": "generate_qwen2_bf16",
+                     "llama_long": "generate_long", "qwen2_long": "generate_long_qwen2",
+                     "qwen2_bf16_long": "generate_long_qwen2_bf16"}[family])
+    family = "llama" if family.startswith("llama") else "qwen2"
     for name in [str(x) for x in g["runs"]]:
         over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
         cfg = toy.toy_config(**over)
@@ -194,8 +198,8 @@ def stochastic_cases():
                    acc_ids=_t(g[f"c{ci}_acc_ids"]), acc_num=_t(g[f"c{ci}_acc_num"]), after_random=float(g[f"c{ci}_after_random"]))
 
 
-def stochastic_runs():
-    g = load_golden("verify_stochastic")
+def stochastic_runs(long=False):
+    g = load_golden("verify_stochastic_long" if long else "verify_stochastic")
     for name in [str(x) for x in g["runs"]]:
         over = {str(k): int(v) for k, v in zip(g[f"{name}_cfg_keys"], g[f"{name}_cfg_vals"])}
         cfg = toy.toy_config(**over)

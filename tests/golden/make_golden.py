@@ -443,6 +443,62 @@ def gen_verify_stochastic(llama, llama_glide):
         })
     save("verify_stochastic", n_cases=N_STOCHASTIC, runs=np.array(["t_mixed", "t_gqa"], dtype="U32"), **arrays)
 
+def gen_stochastic_long(llama, llama_glide):
+    """One tree_spec_generate(temperature > 0) run in the long regime (prompt 720 > the draft's 512-row window, >= 64 rounds):
+    the reference's T > 0 bookkeeping (no KV compaction, cache_lens without the +1) through a truncating window."""
+    import random
+    arrays = {}
+    # The reference's T > 0 loop raises in the round after one that accepted all gamma levels (llama_glide.py:1081), so a long
+    # run needs a model that never does within its budget: candidates in order, the first that completes is the fixture.
+    cands = [("t_long_mixed_s%d" % i, {}, 47 + i, ag, 720 + 10 * i, 160, [4, 16, 16, 16, 16], 0.8)
+             for i, ag in enumerate([0.05, 0.1, 0.1, 0.15, 0.15, 0.2, 0.2, 0.3])]
+    runs = []
+    for name, over, wseed, agree, plen, glen, shape, T in cands:
+        if runs:
+            break
+        cfg = toy.toy_config(**over)
+        tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
+        m = build_ref_model(llama, llama_glide, cfg, tgt, drf)
+        install_triton_stubs()
+        ids = toy.make_prompt(cfg, plen, 100 + wseed)
+        pl = torch.tensor([plen])
+        trace = {"acc_ids": [], "acc_num": []}
+        orig = m.verify_stochastic
+
+        def spy(*a, _orig=orig, _tr=trace, **k):
+            r = _orig(*a, **k)
+            pad = torch.full((1, 8), -1, dtype=torch.int64)
+            pad[:, :r[0].shape[1]] = r[0]
+            _tr["acc_ids"].append(pad)
+            _tr["acc_num"].append(r[1].clone())
+            return r
+
+        m.verify_stochastic = spy
+        random.seed(7000 + wseed)
+        torch.manual_seed(8000 + wseed)
+        try:
+            with torch.inference_mode():
+                out, count, num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=shape, max_gen_len=glen, temperature=T)
+        except RuntimeError as e:
+            print(f"[{name}] SKIPPED: the reference raised after {len(trace['acc_num'])} rounds ({str(e)[:60]}...)")
+            continue
+        print(f"[{name}] T={T} count={int(count)} num={int(num)} rounds={len(trace['acc_num'])}")
+        if len(trace["acc_num"]) < 64:
+            print(f"[{name}] SKIPPED: fewer than 64 rounds")
+            continue
+        runs.append(name)
+        arrays.update({
+            f"{name}_cfg_keys": np.array(sorted(over.keys()), dtype="U32"),
+            f"{name}_cfg_vals": np.array([over[k] for k in sorted(over.keys())], dtype=np.int64),
+            f"{name}_wseed": wseed, f"{name}_agreement": agree, f"{name}_prompt_len": plen, f"{name}_max_gen_len": glen,
+            f"{name}_tree_shape": np.array(shape), f"{name}_temperature": T,
+            f"{name}_weights_checksum": np.frombuffer((toy.state_checksum(tgt) + toy.state_checksum(drf)).encode(), dtype=np.uint8),
+            f"{name}_prompt": ids, f"{name}_out": out, f"{name}_count": int(count), f"{name}_num": int(num),
+            f"{name}_tr_acc_ids": torch.cat(trace["acc_ids"], 0), f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
+        })
+    save("verify_stochastic_long", n_cases=0, runs=np.array(runs, dtype="U32"), **arrays)
+
+
 def gen_chain_stochastic(llama, llama_glide):
     """spec_generate(temperature > 0) end to end (llama_glide.py:715-736): rejection sampling of the greedy chain draft against
     the target's distribution.  Randomness = torch's global CPU generator: per round one rand_like [b, gamma] (fp32), then
@@ -580,13 +636,14 @@ def build_ref_qwen2(qwen2, qwen2_glide, cfg, tgt_sd, drf_sd, dtype=torch.float16
     return m
 
 
-def gen_generate(llama, llama_glide, family="llama"):
+def gen_generate(llama, llama_glide, family="llama", runs=None, out_name=None):
     arrays = {}
     bf16 = family == "qwen2_bf16"             # the QwQ configuration runs in bfloat16 (inference_qwq.py)
     if bf16:
         family = "qwen2"
     if family == "qwen2":
         qwen2, qwen2_glide = import_reference_qwen2()
+    long_runs = runs
     runs = [
         # name, cfg overrides, weight seed, agreement, prompt len, max_gen_len, tree_shape
         ("rand", {}, 11, 1.0, 300, 40, [4, 16, 16, 16, 16]),
@@ -608,7 +665,15 @@ def gen_generate(llama, llama_glide, family="llama"):
                  0.012, 150, 40, [4, 16, 16, 16, 16]),
                 ("qwen_bf16_g7", {"attention_bias": 1, "hidden_size": 896, "num_attention_heads": 7, "num_key_value_heads": 1}, 32,
                  0.012, 120, 36, [4, 8, 8])]
+    if long_runs is not None:
+        runs = long_runs
+    skipped = []
+    kept = {}
     for name, over, wseed, agree, plen, glen, shape in runs:
+        kind = name.rsplit("_s", 1)[0]
+        if long_runs is not None and kept.get(kind, 0) >= LONG_KEEP_BY_KIND.get(kind, LONG_KEEP):
+            skipped.append(name)                  # a spare candidate that was not needed
+            continue
         cfg = toy.toy_config(**over)
         tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)
         if family == "qwen2":
@@ -656,8 +721,19 @@ def gen_generate(llama, llama_glide, family="llama"):
         if kw:                       # stopped on eos: the loops agree up to and including the first eos
             n_eos = int((v_out[0] == kw["eos_id"]).nonzero()[0]) + 1
             n_tok, n_cmp = min(n_tok, n_eos), min(n_cmp, n_eos)
+        if long_runs is not None and not (torch.equal(v_out[0, :n_tok], t_out[0, :n_tok])
+                                          and torch.equal(v_out[0, :n_cmp], s_out[0, :n_cmp])):
+            # the lossless property holds up to fp16 near-ties of the target's two best logits (a 74-row pass and a one-row
+            # pass round differently); over hundreds of tokens a toy model meets one now and then.  Such a run cannot be
+            # replayed bit for bit by ANY other correct implementation either, so it is not a usable golden: say so and
+            # skip it (the seed list holds spares; the run names that made it are what the tests iterate over).
+            d = int((v_out[0, :n_tok] != t_out[0, :n_tok]).nonzero()[0]) if not torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]) else -1
+            print(f"[{name}] SKIPPED: the reference's own speculative run leaves its vanilla run (tree at {d}) -- near-tie")
+            skipped.append(name)
+            continue
         assert torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]), f"{name}: tree != vanilla"
         assert torch.equal(v_out[0, :n_cmp], s_out[0, :n_cmp]), f"{name}: chain != vanilla"
+        kept[kind] = kept.get(kind, 0) + 1
         print(f"[{name}] tree: count={int(t_count)} num={int(t_num)} tau={(n_tok) / int(t_num):.2f};"
               f" chain: count={int(s_count)} num={int(s_num)}")
         arrays.update({
@@ -677,8 +753,47 @@ def gen_generate(llama, llama_glide, family="llama"):
             f"{name}_tr_acc_num": torch.cat(trace["acc_num"], 0),
             f"{name}_tr_cache_lens": torch.cat(trace["cache_lens"], 0),
         })
-    save("generate" if family == "llama" else ("generate_qwen2_bf16" if bf16 else "generate_qwen2"),
-         runs=np.array([r[0] for r in runs], dtype="U32"), **arrays)
+    save(out_name or ("generate" if family == "llama" else ("generate_qwen2_bf16" if bf16 else "generate_qwen2")),
+         runs=np.array([r[0] for r in runs if r[0] not in skipped], dtype="U32"), **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# G-e/G-f in the regime every BASELINE configuration runs in: the draft's 512-row window
+# (llama_glide.py:262,300) truncates from round 1 (prompt >= 700) and the loop runs >= 64 rounds
+# (>= 200 generated tokens), so draft_cache_lens / target_cache_lens_for_draft (:1027,1076,1104)
+# are pinned inside the loop, not only per operator.  Three seeds per weight kind.
+# --------------------------------------------------------------------------- #
+_GQA = {"hidden_size": 512, "num_attention_heads": 4, "num_key_value_heads": 2}
+_QG7 = {"attention_bias": 1, "hidden_size": 896, "num_attention_heads": 7, "num_key_value_heads": 1}
+_QG5 = {"attention_bias": 1, "hidden_size": 640, "num_attention_heads": 5, "num_key_value_heads": 1}
+# (name, cfg overrides, weight seed, agreement, prompt len, max_gen_len, tree_shape); candidates are tried in order and
+# the first LONG_KEEP of each kind whose reference run is tie-free are kept (a skipped candidate is reported, see gen_generate)
+_T5 = [4, 16, 16, 16, 16]
+LONG_KEEP = 3
+LONG_RUNS = {
+    "llama": [[("long_mixed_s%d" % i, {}, 41 + i, 0.04, pl, gl, _T5)
+               for i, (pl, gl) in enumerate([(700, 224), (777, 208), (1030, 216), (905, 208), (1200, 224), (840, 208)])],
+              [("long_gqa_s%d" % i, _GQA, 61 + i, 0.02, pl, gl, _T5)
+               for i, (pl, gl) in enumerate([(720, 216), (801, 208), (1100, 224), (950, 208), (1300, 216), (760, 208)])]],
+    "qwen2": [[("long_qwen_g7_s%d" % i, _QG7, 81 + i, 0.02, pl, gl, _T5)
+               for i, (pl, gl) in enumerate([(710, 208), (1040, 216), (880, 208), (790, 208)])][:4],
+              [("long_qwen_g5_s%d" % i, _QG5, 91 + i, 0.02, pl, gl, _T5)
+               for i, (pl, gl) in enumerate([(830, 208), (745, 216), (990, 208)])]],
+    # bf16 logits carry 8 bits: over 200 tokens nearly every toy model meets a tie between its two best logits somewhere
+    # (three candidates at agreement 0.01 all did, at tokens 12 / 43 / 42); a weaker coupling keeps the margins wider
+    "qwen2_bf16": [[("long_qwen_bf16_g5_s%d" % i, _QG5, 101 + i, ag, pl, gl, _T5)
+                    for i, (pl, gl, ag) in enumerate([(730, 208, 0.01), (860, 208, 0.01), (1010, 208, 0.01), (730, 208, 0.004),
+                                                      (860, 208, 0.004), (1010, 208, 0.004), (790, 208, 0.002),
+                                                      (900, 208, 0.002), (1100, 208, 0.002)])]],
+}
+LONG_KEEP_BY_KIND = {"long_qwen_g7": 2, "long_qwen_g5": 1, "long_qwen_bf16_g5": 1}
+
+
+def gen_generate_long(llama, llama_glide, families=("llama", "qwen2", "qwen2_bf16")):
+    for fam in families:
+        gen_generate(llama, llama_glide, family=fam, runs=[r for kind in LONG_RUNS[fam] for r in kind],
+                     out_name={"llama": "generate_long", "qwen2": "generate_long_qwen2",
+                               "qwen2_bf16": "generate_long_qwen2_bf16"}[fam])
 
 
 # --------------------------------------------------------------------------- #
@@ -784,6 +899,13 @@ def main():
     if "--only-decoding-torch" in sys.argv:
         gen_decoding_torch(llama)
         return
+    if "--only-long" in sys.argv:             # add the long-run fixtures without touching the others
+        fams = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--family=")] or ["llama", "qwen2", "qwen2_bf16"]
+        gen_generate_long(llama, llama_glide, fams)
+        return
+    if "--only-stochastic-long" in sys.argv:
+        gen_stochastic_long(llama, llama_glide)
+        return
     if "--only-qwen2-bf16" in sys.argv:
         gen_generate(llama, llama_glide, family="qwen2_bf16")
         return
@@ -797,6 +919,8 @@ def main():
     gen_decoding_torch(llama)
     gen_generate(llama, llama_glide)
     gen_generate(llama, llama_glide, family="qwen2")
+    gen_generate_long(llama, llama_glide)
+    gen_stochastic_long(llama, llama_glide)
     gen_baselines(llama, llama_glide)
     gen_chain_stochastic(llama, llama_glide)
     install_triton_stubs()          # after model construction

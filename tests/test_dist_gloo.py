@@ -23,6 +23,11 @@ def _free_port():
     return p
 
 
+def _find_run(run_name):
+    fam = "llama_long" if run_name.startswith("long_") else "llama"
+    return [r for r in cases.generate_runs(fam) if r["name"] == run_name][0]
+
+
 def _worker(rank, world, port, run_name, q, sharded_prefill=False, vocab_chunk=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -34,7 +39,7 @@ def _worker(rank, world, port, run_name, q, sharded_prefill=False, vocab_chunk=N
     if vocab_chunk:          # the toy vocabulary (512) is one 8192-chunk: a smaller unit makes every rank own a real slice
         KVShard.VOCAB_CHUNK = vocab_chunk
     from longspec_amd.llama_glide import LlamaGlide
-    run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
+    run = _find_run(run_name)
     m = LlamaGlide(run["cfg"], ops=oracle_ops)
     m.load_state_dict({**run["target_sd"], **{"glide." + k: v for k, v in run["draft_sd"].items()}}, strict=True)
     P = run["prompt_len"]
@@ -124,11 +129,14 @@ def test_vocab_slices_tile_the_vocabulary():
             assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
-@pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree"), (8, "gqa_mixed")])
+# long_*: VERDICT r4 item 1 -- a world-2 run in the regime of the BASELINE configurations (prompt 777 / 801 > the draft's
+# 512-row window, 96 / 89 rounds), token- and count-exact against the reference's single-process run
+@pytest.mark.parametrize("world,run_name", [(2, "mixed"), (3, "gqa_mixed"), (2, "mixed_small_tree"), (8, "gqa_mixed"),
+                                            (2, "long_mixed_s1"), (2, "long_gqa_s1")])
 def test_sequence_sharded_prefill_and_decode_match_single_process(world, run_name):
     """``tree_spec_generate(..., shard=...)`` prefills rank-locally (one K/V all-gather per layer) and
     decodes sharded; token ids and counters equal the single-process golden run on every rank."""
-    run = [r for r in cases.generate_runs() if r["name"] == run_name][0]
+    run = _find_run(run_name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

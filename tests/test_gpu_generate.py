@@ -71,6 +71,35 @@ def test_graph_replayed_rounds_match_reference(run):
     assert torch.equal(t2.cpu(), run["tree_out"])
 
 
+# The regime every BASELINE configuration runs in: prompt >= 700 tokens -- the draft's 512-row window
+# truncates from round 1 --, >= 64 rounds, three seeds per weight kind (tests/golden/make_golden.py::gen_generate_long)
+RUNS_LONG = (list(cases.generate_runs("llama_long")) + list(cases.generate_runs("qwen2_long"))
+             + list(cases.generate_runs("qwen2_bf16_long")))
+
+
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("run", RUNS_LONG, ids=lambda r: r["name"])
+def test_long_runs_match_reference(run, graphs):
+    """Tree and chain decoding on the HIP kernels through a truncating draft window for 89-158 rounds: token ids, `count` and
+    `num` of the reference's runs, exact -- launch by launch and with every round replayed from a HIP graph."""
+    m = build(run)
+    if graphs:
+        m.GRAPH_AFTER = 0
+    ids = run["prompt"].cuda()
+    pl = torch.tensor([run["prompt_len"]], device="cuda")
+    kw = dict(max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
+    assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"]), "acceptance differs from the reference's"
+    assert torch.equal(t_out.cpu(), run["tree_out"])
+    s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, **kw)
+    assert (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
+    n = min(int(s_count) + int(s_num), run["max_gen_len"])
+    assert torch.equal(s_out[:, :n].cpu(), run["chain_out"][:, :n])
+    if not graphs:
+        v_out, v_num, _ = m.vanilla_generate(ids, pl, **kw)
+        assert torch.equal(v_out.cpu(), run["vanilla_out"]) and v_num == run["vanilla_num"]
+
+
 @pytest.mark.parametrize("run", list(cases.baseline_runs()), ids=lambda r: r["name"])
 def test_magicdec_baseline_matches_reference(run):
     m = build(run)
@@ -118,7 +147,7 @@ def test_bf16_generate_matches_reference(run):
     assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
 
 
-@pytest.mark.parametrize("run", list(cases.stochastic_runs()), ids=lambda r: r["name"])
+@pytest.mark.parametrize("run", list(cases.stochastic_runs()) + list(cases.stochastic_runs(long=True)), ids=lambda r: r["name"])
 def test_tree_spec_generate_with_temperature_matches_reference(run):
     """temperature > 0 end to end on the HIP kernels: the reference's seeded run of
     tree_spec_generate(temperature=T) -- output_ids, count, num and every round's (acc_ids, acc_num) -- token for token."""

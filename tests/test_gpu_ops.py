@@ -740,6 +740,41 @@ def test_saturating_keys_are_corrected_in_the_launch(ops, L, nats, nhot):
     assert us_hot <= 1.3 * us_plain, f"{us_hot:.1f} us with saturating keys vs {us_plain:.1f} us without"
 
 
+@pytest.mark.parametrize("late", [True, False])
+def test_saturating_key_behind_the_noted_blocks(ops, late):
+    """the bitmap of blocks to correct covers 2048 blocks = 65536 keys of ONE split.  With a forced single
+    split over more keys than that (or a batched prompt call with > 64k keys per split) a saturated numerator in a later block
+    used to be OR-ed past the bitmap and never corrected -- and because MODE.FP16_OVFL clamps instead of producing inf, the old
+    non-finite redo did not fire either: 65504 stand-ins stayed in O and l.  Now such a block takes the true-maxima redo of the
+    split (late=True: exactly one workgroup per kv head redoes); a hot key inside the bitmap's range is corrected in the
+    launch as before (late=False: no redo).  Both equal the oracle."""
+    from oracle import c_port
+    from longspec_amd import _C
+    H, Hkv, L = 8, 2, 65536 + 4096 + 37
+    q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 4711, a=4)
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    kc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    vc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    kc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).half()
+    vc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).half()
+    u = torch.zeros(128)
+    u[:16] = 1.0
+    a, nats = 2.0, 25.0
+    q = (q.float() + a * u).half()
+    pos = torch.tensor([65536 + 1500, 65536 + 3000] if late else [40000, 65000])
+    kc[0, pos] = (kc[0, pos].float() + nats / (a * 16.0 / 128 ** 0.5) * u).half()
+    cl = torch.tensor([L], dtype=torch.int32)
+    lib = _C.load()
+    lib.ls_attn_redo_count(1)
+    out = ops.verify_attention(g(q), g(k), g(v), g(kc), g(vc), g(cl), ops.pack_tree_mask(g(tm)), False, kv_len_hint=L, n_splits=1)
+    torch.cuda.synchronize()
+    redo = lib.ls_attn_redo_count(1)
+    ref = c_port.verify_attention(q, k, v, kc.clone(), vc.clone(), L, tm, False)
+    worst, _ = assert_close_rel(out, ref, ulps=2.0, what=f"hot key {'behind' if late else 'inside'} the saturation bitmap")
+    print(f"one split of {L} keys, hot keys at {pos.tolist()}: redone splits {redo}, worst |diff| / bound {worst:.2f}")
+    assert redo == (Hkv if late else 0)
+
+
 @pytest.mark.parametrize("sq,L,nats,nhot", [(1, 16384, 14.0, 8), (4, 16384, 30.0, 5), (16, 16421, 14.0, 64), (4, 131072, 18.0, 16)])
 def test_general_kernel_raises_its_reference_in_the_loop(ops, sq, L, nats, nhot):
     """The draft cross-attention / one-row decode shapes (attn_partial_kernel) used to rerun a split in textbook form when a

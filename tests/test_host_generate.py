@@ -92,6 +92,80 @@ def test_chain_spec_generate_matches_reference(run):
     assert torch.equal(out[:, :n], run["chain_out"][:, :n])
 
 
+# The regime every BASELINE configuration runs in: prompt >= 700 tokens -- the draft's 512-row window
+# (llama_glide.py:262,300) truncates from round 1, so draft_cache_lens / target_cache_lens_for_draft (:1027,1076,1104) are
+# compared with the reference INSIDE the loop -- and >= 64 rounds; three seeds per weight kind, Llama and Qwen2 twins, bf16.
+RUNS_LONG = (list(cases.generate_runs("llama_long")) + list(cases.generate_runs("qwen2_long"))
+             + list(cases.generate_runs("qwen2_bf16_long")))
+
+
+def _acc_trace_spy(m, trace):
+    orig = m.ops.tree_collapse
+
+    class Spy:
+        def __getattr__(self, name):
+            return getattr(oracle_ops, name)
+
+        @staticmethod
+        def tree_collapse(*a, **k):
+            r = orig(*a, **k)
+            trace.append(r[1].clone())
+            return r
+
+    m.ops = Spy()
+
+
+@pytest.mark.parametrize("run", RUNS_LONG, ids=lambda r: r["name"])
+def test_long_runs_match_reference(run):
+    """Token ids, `count`, `num` and the per-round acceptance trace of tree decoding, and ids / counters of chain decoding, on
+    the long runs -- exact.  (A bug in the window bookkeeping cannot change token ids -- verification is lossless -- but it
+    lowers the acceptance: `num` and the per-round `acc_num` trace are what pin it.)"""
+    m = build(run)
+    pl = torch.tensor([run["prompt_len"]])
+    kw = dict(max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    assert run["prompt_len"] >= 700 and run["tree_num"] >= 64
+    trace = []
+    _acc_trace_spy(m, trace)
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(run["prompt"], pl, tree_shape=run["tree_shape"], **kw)
+    assert (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
+    assert torch.equal(torch.cat(trace, 0), run["tr_acc_num"])
+    assert torch.equal(t_out, run["tree_out"])
+    n = int(t_count) + int(t_num)
+    assert torch.equal(t_out[0, :n], run["vanilla_out"][0, :n])          # lossless
+    m.ops = oracle_ops
+    s_out, s_count, s_num, _, _ = m.spec_generate(run["prompt"], pl, gamma=4, **kw)
+    assert (int(s_count), int(s_num)) == (run["chain_count"], run["chain_num"])
+    n = min(int(s_count) + int(s_num), run["max_gen_len"])
+    assert torch.equal(s_out[:, :n], run["chain_out"][:, :n])
+
+
+@pytest.mark.parametrize("run", list(cases.stochastic_runs(long=True)), ids=lambda r: r["name"])
+def test_long_tree_run_with_temperature_matches_reference(run):
+    """tree_spec_generate(temperature = 0.8) through a truncating draft window for >= 64 rounds: the reference's seeded run."""
+    import random
+    m = build(run)
+    trace = {"ids": [], "num": []}
+    orig = m.verify_stochastic
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        pad = torch.full((1, 8), -1, dtype=torch.int64)
+        pad[:, :r[0].shape[1]] = r[0]
+        trace["ids"].append(pad)
+        trace["num"].append(r[1].clone())
+        return r
+
+    m.verify_stochastic = spy
+    random.seed(7000 + run["wseed"])
+    torch.manual_seed(8000 + run["wseed"])
+    out, count, num, _, _ = m.tree_spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), tree_shape=run["tree_shape"],
+                                                 max_gen_len=run["max_gen_len"], temperature=run["temperature"])
+    assert torch.equal(torch.cat(trace["num"], 0), run["tr_acc_num"])
+    assert torch.equal(torch.cat(trace["ids"], 0), run["tr_acc_ids"])
+    assert (int(count), int(num)) == (run["count"], run["num"])
+    assert torch.equal(out, run["out"])
+
+
 BASELINES = list(cases.baseline_runs())
 
 
