@@ -218,6 +218,11 @@ class LlamaGlide(LlamaForCausalLM):
     GRAPH_AFTER = 256        # ... once a generation has run this many rounds: a capture costs ~10 ms and a replay saves
                              # <= 0.1 ms on a fast host (more on a slow or busy one), so only long generations
                              # (LongSpec's long-CoT case) pay it back; benchmarks capture up front (prepare_tree_graphs)
+    GRAPH_TIER = 4096        # a captured round / step is sized (host-side bounds of the KV lengths -> launch grids, split
+                             # counts, kernel choice) for the tokens emitted so far rounded up to the next multiple of this;
+                             # a generation that outgrows its tier drops its graphs and captures the next tier's (a 20 000-token
+                             # long-CoT generation: five tiers, ~12 captures of ~10 ms).  Sizing every graph for the whole
+                             # budget instead made a 1k-token prompt with a 20k budget run 21k-row launch shapes from round 1.
 
     # ------------------------------------------------------------------------------------------
     def set_max_gen_len(self, max_gen_len):
@@ -304,7 +309,8 @@ class LlamaGlide(LlamaForCausalLM):
         from types import SimpleNamespace
         dev = output_ids.device
         vs = SimpleNamespace(output_ids=output_ids, cache_lens=cache_lens, input_len=input_len, P=prompt_bound, step=0,
-                             rows=torch.arange(output_ids.size(0), device=dev), graph=None, graph_stream=None)
+                             rows=torch.arange(output_ids.size(0), device=dev), graph=None, graph_stream=None,
+                             graph_bound=0, graph_captures=0)
         vs.use_graphs = bool(dev.type == "cuda" and self.model.layers[-1].self_attn.shard is None and self.GRAPH_ROUNDS)
         return vs
 
@@ -322,10 +328,14 @@ class LlamaGlide(LlamaForCausalLM):
         vs.step += 1
         if vs.use_graphs:
             try:
+                if vs.graph is not None and vs.step + 1 > vs.graph_bound:     # (step s reads s rows beyond the prompt's)
+                    vs.graph = None                                           # outgrown: capture the next tier's step
                 if vs.graph is None and vs.step > self.GRAPH_AFTER:
-                    self._set_hints(vs.P + vs.output_ids.size(1), vs.P + vs.output_ids.size(1))
+                    vs.graph_bound = self._tier_bound(vs.step + 1, vs.output_ids.size(1))
+                    self._set_hints(vs.P + vs.graph_bound, vs.P + vs.graph_bound)
                     cur = torch.cuda.current_stream()
-                    vs.graph_stream = torch.cuda.Stream()
+                    if vs.graph_stream is None:
+                        vs.graph_stream = torch.cuda.Stream()
                     vs.graph_stream.wait_stream(cur)
                     with torch.cuda.stream(vs.graph_stream):          # warm the capture stream's workspaces
                         self._vanilla_device(vs)
@@ -334,6 +344,7 @@ class LlamaGlide(LlamaForCausalLM):
                     with torch.cuda.graph(graph, stream=vs.graph_stream):
                         self._vanilla_device(vs)
                     vs.graph = (graph, self.ops.workspace_tensors() if hasattr(self.ops, "workspace_tensors") else None)
+                    vs.graph_captures += 1
                     return                                            # the warm-up step was this call's token
                 if vs.graph is not None:
                     vs.graph[0].replay()
@@ -621,6 +632,8 @@ class LlamaGlide(LlamaForCausalLM):
         sh = self.model.layers[-1].self_attn.shard
         st.use_graphs = bool(dev.type == "cuda" and (sh is None or sh.graph_safe) and self.GRAPH_ROUNDS)
         st.graphs, st.graph_stream, st.graph_pool, st.graphs_forced = {}, None, None, False
+        st.graph_bound = self._tier_bound(1, max_gen_len)      # emitted-token bound the captured rounds are sized for
+        st.graph_tiers, st.graph_captures = 1, 0               # diagnostics (tools/e2e_fullsize.py, the soak test)
         st.tree_mask = torch.zeros((bsz, Fn, Fn), dtype=torch.int64, device=dev)
         st.tree_mask[:, :, 0] = 1
         st.history_logp_sum = torch.zeros((bsz, Fn), dtype=torch.float32, device=dev)
@@ -668,9 +681,17 @@ class LlamaGlide(LlamaForCausalLM):
             return False
         return True
 
+    def _tier_bound(self, emitted: int, total: int) -> int:
+        """Emitted-token bound of the graph tier that holds `emitted` (GRAPH_TIER; the whole budget when tiers are off)."""
+        tier = self.GRAPH_TIER
+        if not tier or tier <= 0:
+            return total
+        return min(total, (emitted // tier + 1) * tier)
+
     def _graph_hints(self, st):
-        # grid bounds of the whole generation, so that a captured round stays valid until the end
-        self._set_hints(st.P + st.output_ids.size(1) + st.R, st.P + st.output_ids.size(1) + st.Fn)
+        # grid bounds of the current tier, so that a captured round stays valid until the generation leaves it
+        bound = getattr(st, "graph_bound", None) or st.output_ids.size(1)
+        self._set_hints(st.P + bound + st.R, st.P + bound + st.Fn)
 
     def _graph_warm(self, st, a: int):
         """Run the round eagerly ON the capture stream (the operator layer's workspaces are per stream; lazy
@@ -696,6 +717,7 @@ class LlamaGlide(LlamaForCausalLM):
         # the graph holds raw pointers into the per-stream workspaces of the operator layer
         keep = self.ops.workspace_tensors() if hasattr(self.ops, "workspace_tensors") else None
         st.graphs[a] = (graph, state, keep)
+        st.graph_captures += 1
         return st.graphs[a]
 
     def _graph_round(self, st, a: int):
@@ -704,6 +726,10 @@ class LlamaGlide(LlamaForCausalLM):
         round has to run eagerly."""
         if st.graphs is False:
             return None
+        if st.emitted > st.graph_bound:          # the generation has outgrown the tier its graphs were sized for
+            st.graph_bound = self._tier_bound(st.emitted, st.output_ids.size(1))
+            st.graphs = {}
+            st.graph_tiers += 1
         try:
             g = st.graphs.get(a)
             if g is None:
@@ -727,6 +753,9 @@ class LlamaGlide(LlamaForCausalLM):
         if not st.use_graphs or st.graphs is False:
             return
         st.graphs_forced = True
+        if st.emitted > st.graph_bound:
+            st.graph_bound = self._tier_bound(st.emitted, st.output_ids.size(1))
+            st.graphs = {}
         names = ("cache_lens", "target_cache_lens_for_draft", "draft_cache_lens", "tree_mask", "all_spec", "history_logp_sum",
                  "acc_pad", "output_ids", "emitted_dev")
         try:

@@ -199,3 +199,66 @@ def test_spec_generate_with_temperature_matches_reference(run):
         ops.stochastic_chain_noise_fn = None
     assert (int(count), int(num)) == (run["count"], run["num"])
     assert torch.equal(out.cpu(), run["out"])
+
+
+def test_soak_long_generation_crosses_graph_tiers():
+    """a long generation at toy dimensions -- >= 2000 graph-replayed rounds, the KV growing from 3000 to
+    > 9000 rows across six graph tiers (LlamaGlide.GRAPH_TIER = 1024 here: the captured rounds are re-sized and re-captured
+    every time the generation outgrows its tier), GQA-4 x 74 verification rows on the warp-specialised kernel.
+    Checked without reference to a second run: EVERY emitted token must be the target's arg-max given its own prefix
+    (one teacher-forced pass over prompt + output), up to fp16 near-ties -- the lossless property itself; and against
+    `vanilla_generate` from the same prompt: identical up to the first position where the target's two best logits are within
+    two fp16 ulps (random toy weights meet such a tie every few hundred tokens; the reference's own runs do too, see
+    make_golden.py::gen_generate_long)."""
+    import toy
+    from longspec_amd.llama_glide import LlamaGlide
+    cfg = toy.toy_config(hidden_size=512, num_attention_heads=4, num_key_value_heads=1, max_position_embeddings=32768)
+    tgt, drf = toy.make_weights(cfg, 91, agreement=0.04)
+    m = LlamaGlide(cfg, device="cuda")
+    m.load_state_dict({**tgt, **{"glide." + k: v for k, v in drf.items()}}, strict=True)
+    m.GRAPH_AFTER, m.GRAPH_TIER = 0, 1024
+    P, G = 3000, 6200
+    ids = toy.make_prompt(cfg, P, 191).cuda()
+    pl = torch.tensor([P], device="cuda")
+    states, orig_begin = [], m.begin_tree_decode
+
+    def begin(*a, **k):
+        states.append(orig_begin(*a, **k))
+        return states[-1]
+
+    m.begin_tree_decode = begin
+    t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, max_gen_len=G, eos_id=-1)
+    m.begin_tree_decode = orig_begin
+    st = states[0]
+    n = int(t_count) + int(t_num)
+    assert int(t_num) >= 2000, f"only {int(t_num)} rounds"
+    assert st.use_graphs and st.graphs is not False, "the rounds did not replay from HIP graphs"
+    assert st.graph_tiers >= 3 and st.graph_captures >= 3 * 2, (st.graph_tiers, st.graph_captures)
+    assert n >= G - 7
+    # ---- every emitted token is the target's arg-max given its own prefix (teacher forcing), up to near-ties
+    full = torch.cat([ids, t_out[:, :n - 1]], dim=1)
+    m.set_max_gen_len(64)
+    m._set_hints(full.size(1), full.size(1))
+    with torch.inference_mode():
+        h = m.model.forward(full, exec_type="prefill").last_hidden_state
+        lg = m.lm_head(h[:, P - 1:]).float()[0]                       # row i: the logits that choose t_out[i]
+    top = lg.max(dim=-1)
+    chosen = lg.gather(1, t_out[0, :n, None]).squeeze(1)
+    ulp = top.values.abs().clamp_min(2.0 ** -14).log2().floor().sub(10).exp2()
+    gap = (top.values - chosen) / ulp
+    exact = int((top.indices == t_out[0, :n]).sum())
+    print(f"soak: {int(t_num)} rounds, {n} tokens, tau {n / int(t_num):.2f}, tiers {st.graph_tiers}, captures {st.graph_captures}; "
+          f"teacher-forced arg-max equal at {exact}/{n} positions, worst gap {gap.max().item():.2f} ulp")
+    assert gap.max().item() <= 3.0, f"an emitted token lies {gap.max().item():.1f} ulps below the target's best logit"
+    assert exact >= 0.97 * n
+    # ---- against vanilla decoding from the same prompt: equal up to the first near-tie
+    v_out, _, _ = m.vanilla_generate(ids, pl, max_gen_len=G, eos_id=-1)
+    neq = (t_out[0, :n] != v_out[0, :n]).nonzero()
+    k = n if neq.numel() == 0 else int(neq[0])
+    print(f"soak: tree == vanilla for {k} of {n} tokens")
+    if k < n:
+        a, b = int(t_out[0, k]), int(v_out[0, k])
+        margin = abs(float(lg[k, a] - lg[k, b])) / float(ulp[k])
+        best = float(top.values[k])
+        assert margin <= 3.0 and min(float(lg[k, a]), float(lg[k, b])) >= best - 3.0 * float(ulp[k]), \
+            f"tree and vanilla part at {k} on a margin of {margin:.1f} ulps"
