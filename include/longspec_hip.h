@@ -209,48 +209,6 @@ int ls_linear_fwd(const ls_linear_desc* d, void* workspace, size_t workspace_byt
  * attention finish) occupies the stream, it takes the HBM ramp off the projection that follows. */
 int ls_linear_prefetch(const ls_linear_desc* d, int units, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- one launch between two attention calls of a verification pass ----------------------------------------------------
- * Everything LlamaDecoderLayer.forward does behind the attention of layer i and in front of the attention of layer i + 1
- * (longspec/test/llama.py:390 o_proj, :492 residual add, LlamaRMSNorm post_attention_layernorm, LlamaMLP, :492 again,
- * the next layer's input_layernorm, :361-378 its q/k/v projections + apply_rotary_pos_emb) as ONE persistent kernel:
- * all compute units stay resident, the chain's seams are counter waits inside the launch and the weight stream runs on
- * across them.  Bit-identical to the launches it replaces: ls_linear_fwd (o_proj) -> ls_rmsnorm_fwd(residual) ->
- * ls_linear_fwd(LS_EPI_SILU_MUL) -> ls_linear_fwd (down_proj) -> ls_rmsnorm_fwd(residual) -> ls_linear_fwd(LS_EPI_QKV_ROPE).
- *   resid      in: the residual stream in front of the attention; out: the residual stream behind the MLP ([M, hidden])
- *   xn         out: norm2(resid_out) -- the layer-stack's output rows when n_qkv_seg == 0 (norm2 = the model's final norm)
- *   qkv        out: [M, sum n_qkv] (row stride ld_qkv), q and k rotated; w_qkv[0..1] packed by ls_linear_pack_rope
- * M = 33 .. 80 token rows.  The workspace is DEDICATED to this entry point (one per device; it carries the launch
- * generation between calls) and must be zero-filled once; calls on one stream only.  A wait inside a launch is bounded:
- * ls_layer_tail_status() != 0 means a launch gave up (its workgroups were not all resident -- e.g. another process on the
- * GPU) and every result since then is invalid. */
-typedef struct ls_layer_tail_desc {
-    const void* attn;          /* [M, Ko] dtype, row stride ld_attn: the attention output                  */
-    void* resid;               /* [M, hidden] dtype, row stride ld_res                                      */
-    void* xn;                  /* [M, hidden] dtype, contiguous                                             */
-    const void* w_o;           /* packed [hidden, Ko]          (ls_linear_pack_weight)                      */
-    const void* w_gate_up;     /* packed gate|up [2 inter, hidden] (ls_linear_pack_gate_up)                */
-    const void* w_down;        /* packed [hidden, inter]                                                    */
-    const void* w_qkv[3];      /* the NEXT layer's packed q, k (ls_linear_pack_rope) and v; n_qkv_seg == 0: none */
-    const void* b_qkv[3];      /* biases or NULL                                                            */
-    int32_t n_qkv[3];
-    int32_t n_qkv_seg;
-    void* qkv;
-    int64_t ld_attn, ld_res, ld_qkv;
-    const void* norm1_weight;  /* post_attention_layernorm.weight [hidden]                                  */
-    const void* norm2_weight;  /* the next layer's input_layernorm.weight, or model.norm.weight             */
-    const void* rope_cos;      /* [M, 128] dtype tables of the rows' positions (ls_rope_cos_sin)            */
-    const void* rope_sin;
-    void* ev_start;            /* optional hipEvent_t pair recorded around the launch                       */
-    void* ev_stop;
-    int32_t M, hidden, inter, Ko;
-    int32_t dtype;
-    float norm_eps;
-} ls_layer_tail_desc;
-
-size_t ls_layer_tail_workspace_bytes(const ls_layer_tail_desc* d);   /* 0: unsupported shape (ls_last_error says why) */
-int ls_layer_tail_fwd(const ls_layer_tail_desc* d, void* workspace, size_t workspace_bytes, void* stream);
-int ls_layer_tail_status(const void* workspace);                     /* synchronises the device; 0 = healthy */
-
 /* ---- RMSNorm / RoPE (K8, K9) ------------------------------------------------ */
 
 /* LlamaRMSNorm.forward (transformers; imported at longspec/test/llama.py:36; vendored

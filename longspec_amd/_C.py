@@ -53,21 +53,6 @@ class LinearDesc(C.Structure):
     ]
 
 
-class LayerTailDesc(C.Structure):
-    """Mirror of ``ls_layer_tail_desc`` (include/longspec_hip.h) -- keep field order in sync."""
-    _fields_ = [
-        ("attn", C.c_void_p), ("resid", C.c_void_p), ("xn", C.c_void_p),
-        ("w_o", C.c_void_p), ("w_gate_up", C.c_void_p), ("w_down", C.c_void_p),
-        ("w_qkv", C.c_void_p * 3), ("b_qkv", C.c_void_p * 3), ("n_qkv", C.c_int32 * 3), ("n_qkv_seg", C.c_int32),
-        ("qkv", C.c_void_p),
-        ("ld_attn", C.c_int64), ("ld_res", C.c_int64), ("ld_qkv", C.c_int64),
-        ("norm1_weight", C.c_void_p), ("norm2_weight", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-        ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-        ("M", C.c_int32), ("hidden", C.c_int32), ("inter", C.c_int32), ("Ko", C.c_int32),
-        ("dtype", C.c_int32), ("norm_eps", C.c_float),
-    ]
-
-
 # every symbol include/longspec_hip.h declares: (name, restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int
@@ -90,9 +75,6 @@ SYMBOLS = {
     "ls_linear_workspace_bytes": (C.c_size_t, [C.POINTER(LinearDesc)]),
     "ls_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), _P, C.c_size_t, _P]),
     "ls_linear_prefetch": (C.c_int, [C.POINTER(LinearDesc), _I, _P, C.c_size_t, _P]),
-    "ls_layer_tail_workspace_bytes": (C.c_size_t, [C.POINTER(LayerTailDesc)]),
-    "ls_layer_tail_fwd": (C.c_int, [C.POINTER(LayerTailDesc), _P, C.c_size_t, _P]),
-    "ls_layer_tail_status": (C.c_int, [_P]),
     "ls_topk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ls_logprob_topk": (C.c_int, [_P, _I, _I, _L, _I, _P, _I, _P, _P, _P, C.c_size_t, _P]),
     "ls_argmax_rows": (C.c_int, [_P, _I, _I, _L, _I, _P, _P, C.c_size_t, _P]),

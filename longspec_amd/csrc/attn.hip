@@ -849,6 +849,16 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
 #ifndef LS_WS_HEADROOM
 #define LS_WS_HEADROOM 4
 #endif
+// Diagnostic builds only (tools/build_variant.py abl<N> -DLS_WS_ABLATE=<N>; results are WRONG by construction): parts of the
+// warp-specialised kernel's steady loop removed, to price them at the in-round clock (profiles/r5_attn_ceiling.md).
+//   1 no K/V DMA behind the first look-ahead blocks     2 no QK^T MFMAs     4 no P.V / row-sum MFMAs
+//   8 no soft-max VALU work (a constant P is stored)    16 no LDS fragment reads (K, V^T, P) in the loop
+#ifndef LS_WS_ABLATE
+#define LS_WS_ABLATE 0
+#endif
+#ifndef LS_PART_WT
+#define LS_PART_WT 0
+#endif
 constexpr int WS_HEADROOM = LS_WS_HEADROOM;     // octaves between the first-64-keys maximum and the fixed soft-max reference
 constexpr int WS_QT = 5;                         // row tiles per pair
 constexpr int WS_LA = 5;                         // blocks of DMA look-ahead (80 KB of K+V in flight per CU)
@@ -872,17 +882,30 @@ __device__ __forceinline__ void qk_block_pf(f32x4 (&s)[2][QT], const typename E:
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
+        for (int kt = 0; kt < 2; ++kt) {
+#if LS_WS_ABLATE & 16
+            kf[k4][kt] = qf[0][k4];
+#else
+            kf[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
+#endif
+        }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if LS_WS_ABLATE & 2
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) asm volatile("" ::"v"(kf[k4][kt]));       // (the fragment reads stay)
+#else
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) s[kt][qt] = E::mfma(kf[k4][kt], qf[qt][k4], s[kt][qt]);
+#endif
 }
 
 template <typename E, int QT, bool S_ROLE>           // QT row tiles per pair: 5 (17..20 tiles per row block), 3 (two row chunks of 12 tiles)
@@ -986,7 +1009,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         __builtin_amdgcn_s_barrier();
     };
     auto step_head = [&](int j) {
+#if !(LS_WS_ABLATE & 1)
         if (j + 1 + WS_LA < nblocks) dma(j + 1 + WS_LA);                // its K slot died at step j-1, its V slot at step j-1
+#endif
     };
     auto step_tail = [&](int j) {
         wait_block(j + 2, min(nblocks, j + 2 + WS_LA));                 // K(j+2) is multiplied at step j+1
@@ -1085,11 +1110,17 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 for (int qt = 0; qt < QT; ++qt) {
                     const float mc = mref[qt] * c;
                     typename E::V8 pf;
+#if LS_WS_ABLATE & 8
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = E::from_f32(mc * 0.f + 0.001f * (float)(e + 1));
+                    asm volatile("" ::"v"(sc[0][qt]), "v"(sc[1][qt]));
+#else
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             pf[kt * 4 + e] = E::from_f32(__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][qt][e], c, -mc)));
+#endif
 #ifdef LS_MUTATE_SKIP_BLOCK
                     // MUTANT (tests/test_gpu_ops.py::test_mutant_is_caught, never the product build): one 32-key block of one
                     // split of one kv head contributes nothing
@@ -1289,7 +1320,13 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     const int jj = j - 1;
                     typename E::V8 pf[QT];
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) pf[qt] = lds_read16<typename E::V8>(p_base + (jj & 1) * WS_PBUF_B + qt * 1024);
+                    for (int qt = 0; qt < QT; ++qt) {
+#if LS_WS_ABLATE & 16
+                        pf[qt] = ones;
+#else
+                        pf[qt] = lds_read16<typename E::V8>(p_base + (jj & 1) * WS_PBUF_B + qt * 1024);
+#endif
+                    }
                     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                     int vx = tb.vx;
                     asm volatile("" : "+v"(vx));           // see qk_block
@@ -1301,15 +1338,27 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt) {
                         const unsigned va = vb + ((dt ^ vx) << 5);
+#if LS_WS_ABLATE & 16
+                        vf[dt].v = ones;
+                        asm volatile("" ::"v"(va));
+#else
                         vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
                         vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
+#endif
                     }
+#if LS_WS_ABLATE & 4
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) asm volatile("" ::"v"(vf[dt].v));
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) asm volatile("" ::"v"(pf[qt]));
+#else
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt) acc[dt][qt] = E::mfma(vf[dt].v, pf[qt], acc[dt][qt]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) lacc[qt] = E::mfma(ones, pf[qt], lacc[qt]);
+#endif
                     if constexpr (SAT_FIX) {
                         // a saturated numerator adds >= 65504 to its row's sum: one comparison of the five rows' running total
                         // per step (7 vector instructions; any VALU work in this wave comes out of the SIMD the pair shares --
@@ -1415,7 +1464,16 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         lt > 0.f ? s_inv[pair * 80 + qt * 16 + l15] + __logf(lt) : -INFINITY;
                 float* op = p.parts_o + ((((long)split * p.b + bi) * p.sq + rrow[qt]) * p.H + head) * D + g4 * 4;
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
+                for (int dt = 0; dt < 8; ++dt) {
+#if LS_PART_WT
+                    // diagnostic (-DLS_PART_WT=1, profiles/r5_part_wt.json): the partials leave the L2 as they are written
+                    // (agent-scope write-through) instead of in one write-back burst at the end of the kernel
+                    const f32x4 v_ = acc[dt][qt] * inv;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(op + dt * 16), "v"(v_) : "memory");
+#else
+                    *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
+#endif
+                }
             }
         }
 #ifdef LS_WS_PROF
@@ -1532,6 +1590,18 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     const long part_lse_stride = p.part_lse_stride;
     const long part_o_stride = p.part_o_stride;
     const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
+    // XM == 2: the parts are mailbox slots that PEERS wrote.  The mailbox is uncached device memory, but nothing in the memory
+    // model keeps a line of it out of this CU's L1 (a stale line of epoch e - 2 of the same parity slot would be merged
+    // silently): the record is read with `nt` loads, which bypass the L1 (MI355X_MICROARCH: nt / sc1 loads are
+    // L2-served, 0-3 % slower at 16 bytes), the compiler still counts them.
+    auto ld4 = [](const float* a_) -> f32x4 {
+        if constexpr (XM == 2) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_));
+        else return *reinterpret_cast<const f32x4*>(a_);
+    };
+    auto ld1 = [](const float* a_) -> float {
+        if constexpr (XM == 2) return __builtin_nontemporal_load(a_);
+        else return *a_;
+    };
 
     float lnew = -INFINITY;
     if (p.new_o != nullptr) lnew = p.new_lse[lse_idx];
@@ -1543,15 +1613,15 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         // so the number of dependent load batches is its run time.  Parts beyond n re-read part n-1 with weight 0.
         float l[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) l[u] = parts_lse_[(u < n ? u : n - 1) * part_lse_stride + lse_idx];
+        for (int u = 0; u < 32; ++u) l[u] = ld1(parts_lse_ + (u < n ? u : n - 1) * part_lse_stride + lse_idx);
         f32x4 oa[16], ob[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            oa[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (u < n ? u : n - 1) * part_o_stride + o_idx);
+            oa[u] = ld4(parts_o_ + (u < n ? u : n - 1) * part_o_stride + o_idx);
         if (n > 16) {
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                ob[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (16 + u < n ? 16 + u : n - 1) * part_o_stride + o_idx);
+                ob[u] = ld4(parts_o_ + (16 + u < n ? 16 + u : n - 1) * part_o_stride + o_idx);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -1576,7 +1646,7 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
         // pass 1: reference max over the parts (independent scalar loads)
         float mx = -INFINITY;
 #pragma unroll 8
-        for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, parts_lse_[i * part_lse_stride + lse_idx]);
+        for (int i = 0; i < p.n_parts; ++i) mx = fmaxf(mx, ld1(parts_lse_ + i * part_lse_stride + lse_idx));
         if (joint) mx = fmaxf(mx, lnew);
         mref = mx == -INFINITY ? 0.f : mx;
         // pass 2: weighted sum in fixed part order; branch-free (an empty part has lse = -inf -> weight 0 and
@@ -1587,8 +1657,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             f32x4 o8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                l8[u] = parts_lse_[(i + u) * part_lse_stride + lse_idx];
-                o8[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (i + u) * part_o_stride + o_idx);
+                l8[u] = ld1(parts_lse_ + (i + u) * part_lse_stride + lse_idx);
+                o8[u] = ld4(parts_o_ + (i + u) * part_o_stride + o_idx);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1602,8 +1672,8 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             f32x4 o4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                l4[u] = parts_lse_[(i + u) * part_lse_stride + lse_idx];
-                o4[u] = *reinterpret_cast<const f32x4*>(parts_o_ + (i + u) * part_o_stride + o_idx);
+                l4[u] = ld1(parts_lse_ + (i + u) * part_lse_stride + lse_idx);
+                o4[u] = ld4(parts_o_ + (i + u) * part_o_stride + o_idx);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1613,9 +1683,9 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
             }
         }
         for (; i < p.n_parts; ++i) {
-            const float wgt = expf(parts_lse_[i * part_lse_stride + lse_idx] - mref);
+            const float wgt = expf(ld1(parts_lse_ + i * part_lse_stride + lse_idx) - mref);
             den += wgt;
-            o += *reinterpret_cast<const f32x4*>(parts_o_ + i * part_o_stride + o_idx) * wgt;
+            o += ld4(parts_o_ + i * part_o_stride + o_idx) * wgt;
         }
     }
     if (joint && lnew != -INFINITY) {

@@ -38,6 +38,11 @@
 #include <stdlib.h>
 
 #include "ls_common.h"
+#ifdef LS_WITH_TAIL
+#define LS_TAIL_PART 0
+#include "../../tools/mb/layer_tail_kernel.inc"
+#undef LS_TAIL_PART
+#endif
 
 namespace {
 
@@ -510,651 +515,12 @@ __global__ __launch_bounds__(GEMM_THREADS, MT >= 5 ? 1 : 2) void skinny_gemm_ker
     }
 }
 
-// =====================================================================================================================
-// layer_tail_kernel -- ONE persistent launch for everything between two attention calls of a verification pass
-// (VERDICT r3 item 1).  All CUs run one 256-thread workgroup; the chain's all-to-all seams are counter waits inside
-// the launch, and the weight stream does not stop at a seam: a workgroup requests the first register sets of its NEXT
-// projection before it waits for that projection's input.
-//
-//   P1  o_proj                     split-K partials, row-major fp32 (llama.py:390)
-//   N1  sum of the partials in split order -> dtype, + residual, post_attention_layernorm       (one workgroup per row)
-//   P2  gate|up + SiLU + product   (LlamaMLP; qwen2.py:218-230)
-//   P3  down_proj                  split-K partials
-//   N2  as N1 with the NEXT layer's input_layernorm (or the model's final norm)
-//   P4  the next layer's q|k|v + RoPE (llama.py:361-378), split-K by the slab counters of the stand-alone kernel
-//
-// Arithmetic: every projection keeps the work decomposition of skinny_gemm_kernel -- (64/128-row slab, split of K) items
-// with the plan make_plan() gives the stand-alone launch, wave w the w-th quarter of the item's k-range, the 4 waves
-// summed in wave order, the splits in split order, every projection rounded where nn.Linear rounds -- and the norm is
-// rmsnorm_rows_kernel's (canonical sum of squares): the chain is bit-identical to the eight launches it replaces
-// (tests/test_gpu_tail.py), and a row's values do not depend on M.
-//
-// Visibility (MI355X_MICROARCH "inter-workgroup visibility", recipe R1): data another workgroup reads inside the launch
-// is stored write-through (sc1), every storing wave drains vmcnt(0), one lane bumps an agent-scope counter; a consumer
-// polls that counter relaxed from ONE wave, takes ONE agent acquire (buffer_inv sc1) and reads with plain loads.  Every
-// workgroup arrives exactly once at every counter, so a counter's target is (generation + 1) * G; the generation word is
-// advanced by workgroup 0 at the end of the launch (launches of a stream are ordered, and workgroup 0 cannot get there
-// before every workgroup has read it: its own waits depend on all G arrivals at the first counter).  Waits are bounded:
-// a workgroup that is not resident (another process on the GPU) makes the poll give up and latches sync[1].
-constexpr int TAIL_MP = 80;                   // padded rows of the partial buffers
-constexpr int TAIL_NSYNC = 5;                 // C1 .. C5
-constexpr int TAIL_SYNC_WORDS = 16 + TAIL_NSYNC * 8 * 16;
-
-struct TailW {                                // one projection: packed weights + the stand-alone launch's plan
-    const char* w[3];
-    const char* bias[3];
-    int n[3];
-    int K, nks, N;                            // N = output columns (SiLU: of the product)
-    int nslabs, S, NT;
-};
-
-struct TailK {
-    int M, G;
-    const char* attn;                         // o_proj input [M, o.K]
-    long ld_attn;
-    char* resid;                              // residual stream [M, hidden]: in (before the attention) / out (after the MLP)
-    long ld_res;
-    char* xn;                                 // [M, hidden] normalised rows: N1 -> P2, N2 -> P4 (the launch's output when there is no P4)
-    char* act;                                // [M, inter]
-    float* part;                              // [S][TAIL_MP][hidden] fp32
-    char* qkv;                                // [M, sum n] of the next layer (null: last layer)
-    long ld_qkv;
-    float* qkv_part;
-    unsigned* qkv_counters;
-    const char* norm1_w;
-    const char* norm2_w;
-    float eps;
-    const char* rope_cos;
-    const char* rope_sin;
-    int rope_segs;
-    int hidden, inter;
-    TailW o, gu, down, q;
-    unsigned* sync;                           // [0] generation, [1] error latch, counters from word 16 on (64 B apart)
-    unsigned spin_limit;
-    int flag_off;
-    int n1_rows, n2_rows;                     // rows per workgroup of the two norm phases (1, 2 or 4)
-    int l2_units;                             // units (8 KB per wave) of seam-time L2 prefetch behind the register sets; 0 = off
-    int l2_scratch_off;                       // LDS byte offset of the 1 KB DMA scratch slot
-    unsigned long long* prof;                 // -DLS_TAIL_PROF (tools/tail_prof.py): [G][16] s_memrealtime stamps, else unused
-};
-
-#ifdef LS_TAIL_PROF
-#define TAIL_STAMP(i) do { if (threadIdx.x == 0) p.prof[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TAIL_STAMP(i)
+// (round 4's persistent layer-tail launch lives in tools/mb/layer_tail_kernel.inc: measured not faster, diagnostic variants only)
+#ifdef LS_WITH_TAIL
+#define LS_TAIL_PART 1
+#include "../../tools/mb/layer_tail_kernel.inc"
+#undef LS_TAIL_PART
 #endif
-
-__device__ __forceinline__ unsigned* tail_counter(unsigned* sync, int k, int shard) { return sync + 16 + (k * 8 + shard) * 16; }
-
-// all of this workgroup's write-through stores are acknowledged, then ONE lane counts the workgroup in.  The NEXT projection's
-// weight requests are issued AFTER this (vmcnt is in order: they would be waited for here)
-__device__ __forceinline__ void tail_arrive(unsigned* sync, int k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(tail_counter(sync, k, blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave 0 polls the 8 shards of counter k (one lane each, relaxed) until their sum reaches `target`, takes the agent acquire;
-// the barrier releases the other waves, whose plain loads then see what the arrivals published
-__device__ __forceinline__ void tail_wait(unsigned* sync, int k, unsigned target, unsigned spin_limit, int wave, int lane) {
-    if (wave == 0) {
-        unsigned spins = 0;
-        for (;;) {
-            unsigned v = lane < 8 ? __hip_atomic_load(tail_counter(sync, k, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v = __builtin_amdgcn_readfirstlane(v);
-            if ((int)(v - target) >= 0) break;
-            if (++spins > spin_limit) {                     // a workgroup of the launch is not resident: give up, loudly
-                if (lane == 0) __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-// The streaming core of skinny_gemm_kernel with its register sets in a pool that outlives a projection: `prefetch` issues an
-// item's first LAC sets, `mainloop` consumes them (or issues them itself) and leaves the item's accumulators.
-template <typename E, int MT, int NT, int KPS>
-struct TailCore {
-    using V8 = typename E::V8;
-    static constexpr int UPC = 2 / KPS;
-    static constexpr int LAC = NT == 8 ? (KPS == 1 ? 3 : 1) : 3;
-    static constexpr int NCS = LAC + 1;
-    static constexpr int XL = 2 * MT;
-    static constexpr int XSLAB = MT * 16 * 128;
-    static_assert(NCS * KPS * NT == 32, "every variant uses the same 32-set register pool");
-    static_assert(NCS % UPC == 0, "static x-chunk phase");
-
-    struct Geo {
-        const char* wtile[NT];
-        const char* bias_p;
-        int ch0, nch, nun, quarter;
-        int seg, seg_base, n_lim, n_tile0;
-    };
-
-    // the geometry of item (slab, split) for this wave -- skinny_gemm_kernel's prologue
-    static __device__ __forceinline__ void geo(const TailW& w, bool silu, int slab, int split, int wave, int lane, Geo& g) {
-        const int nch_all = w.nks >> 1;
-        const int ch_begin = (int)(((long)nch_all * split) / w.S);
-        const int ch_end = (int)(((long)nch_all * (split + 1)) / w.S);
-        g.seg_base = 0;
-        g.seg = 0;
-        const long group_b = (long)w.nks * 4096 + GROUP_PAD;
-        const int row0 = slab * NT * 16;
-        if (!silu) {
-            if (row0 >= w.n[0]) { g.seg_base = w.n[0]; g.seg = 1; }
-            if (g.seg == 1 && row0 >= w.n[0] + w.n[1]) { g.seg_base = w.n[0] + w.n[1]; g.seg = 2; }
-            g.bias_p = w.bias[g.seg] ? w.bias[g.seg] - (long)g.seg_base * 2 : nullptr;
-            g.n_tile0 = row0;
-            g.n_lim = g.seg_base + w.n[g.seg];
-        } else {
-            g.bias_p = nullptr;
-            g.n_tile0 = row0 >> 1;
-            g.n_lim = w.n[0];
-        }
-        const int ngroups = !silu ? (w.n[g.seg] + 63) >> 6 : (2 * w.n[0] + 63) >> 6;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int gi = min(((row0 - g.seg_base) >> 6) + (t >> 2), ngroups - 1);
-            g.wtile[t] = w.w[g.seg] + (long)gi * group_b + (t & 3) * 1024 + lane * 16;
-        }
-        const int quarter = (ch_end - ch_begin + 3) >> 2;
-        g.ch0 = ch_begin + wave * quarter;
-        g.nch = max(0, min(ch_end - g.ch0, quarter));
-        g.nun = g.nch * UPC;
-        g.quarter = quarter;
-    }
-
-    static __device__ __forceinline__ void issue_w(V8 (&pool)[32], const Geo& g, int un, int set) {
-#pragma unroll
-        for (int kk = 0; kk < KPS; ++kk)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                pool[(set * KPS + kk) * NT + t] = load_w<V8>(g.wtile[t] + (long)(g.ch0 * 2 + un * KPS + kk) * 4096);
-    }
-
-    static __device__ __forceinline__ void prefetch(V8 (&pool)[32], const Geo& g) {
-#pragma unroll
-        for (int i = 0; i < LAC; ++i)
-            if (i < g.nun) issue_w(pool, g, i, i);
-    }
-
-    // Behind the register sets: `nu` more units of the item's stream are pulled into the XCD's L2 while the workgroup sits at
-    // a seam (the seams take ~10 us -- two counter hops and a norm phase -- and 24 KB per wave of register look-ahead cover 4
-    // of them).  The requests are LDS-DMA writes into a 1 KB scratch slot that nobody reads: no destination register to keep
-    // alive, default cache policy, so the stream's later nt loads hit.  Wave 0 polls the counters -- its own requests would
-    // queue in front of every poll -- so waves 1..3 also touch wave 0's units (unit u by wave 1 + u % 3).
-    static __device__ __forceinline__ void prefetch_l2(const Geo& g, int wave, int quarter_chunks, unsigned lds_scratch, int nu) {
-        auto touch = [&](const char* src) {
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_scratch) : "memory", "m0");
-        };
-        if (wave == 0) return;
-        for (int i = 0; i < nu; ++i) {
-            const int un = LAC + i;
-            if (un < g.nun) {
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) touch(g.wtile[t] + (long)(g.ch0 * 2 + un * KPS + kk) * 4096);
-            }
-            if (un < g.nun && wave == 1 + i % 3) {           // wave 0's unit `un`: its k-range starts `wave` quarters earlier
-                const int ch0_w0 = g.ch0 - wave * quarter_chunks;
-#pragma unroll
-                for (int kk = 0; kk < KPS; ++kk)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) touch(g.wtile[t] + (long)(ch0_w0 * 2 + un * KPS + kk) * 4096);
-            }
-        }
-    }
-
-    static __device__ __forceinline__ void mainloop(V8 (&pool)[32], const Geo& g, const char* x, long ldx, int M, char* xlds,
-                                                    f32x4 (&acc)[NT][MT], bool prefetched, int lane) {
-        const int l15 = lane & 15, g4 = lane >> 4;
-        const int xr_in = lane >> 3, xslot = lane & 7;
-        V8 xs[XL];
-        unsigned xoff[XL];
-#pragma unroll
-        for (int i = 0; i < XL; ++i) xoff[i] = (unsigned)(((long)min(i * 8 + xr_in, M - 1) * ldx + xslot * 8) * 2);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto load_x = [&](int ch) {
-            const char* xc = x + (long)ch * 128;
-#pragma unroll
-            for (int i = 0; i < XL; ++i) xs[i] = *reinterpret_cast<const V8*>(xc + xoff[i]);
-        };
-        auto store_x = [&]() {
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                const int row = i * 8 + xr_in;
-                *reinterpret_cast<V8*>(xlds + row * 128 + ((xslot ^ ((row >> 1) & 7)) << 4)) = xs[i];
-            }
-        };
-        auto mma_unit = [&](int ph, int set) {
-#pragma unroll
-            for (int kk = 0; kk < KPS; ++kk) {
-                const int ks = ph * KPS + kk;
-                V8 bx[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int row = mt * 16 + l15;
-                    bx[mt] = *reinterpret_cast<const V8*>(xlds + row * 128 + (((ks * 4 + g4) ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = E::mfma(pool[(set * KPS + kk) * NT + t], bx[mt], acc[t][mt]);
-            }
-        };
-        const int nun = g.nun, nch = g.nch, ch0 = g.ch0;
-        if (nch > 0) load_x(ch0);
-        if (!prefetched) prefetch(pool, g);
-        int c = 0;
-        for (; c + NCS - 1 + LAC < nun; c += NCS) {
-#pragma unroll
-            for (int u = 0; u < NCS; ++u) {
-                if (u % UPC == 0) {
-                    store_x();
-                    load_x(ch0 + (c + u) / UPC + 1);
-                }
-                issue_w(pool, g, c + u + LAC, (u + LAC) % NCS);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_unit(u % UPC, u);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NCS + LAC - 1; ++u) {
-            if (c + u < nun) {
-                if (u % UPC == 0) {
-                    store_x();
-                    if ((c + u) / UPC + 1 < nch) load_x(ch0 + (c + u) / UPC + 1);
-                }
-                if (c + u + LAC < nun) issue_w(pool, g, c + u + LAC, (u + LAC) % NCS);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_unit(u % UPC, u % NCS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-};
-
-// one row of N1 / N2: y = dtype(sum of the S split partials, split order); h = dtype(residual + y) -> residual stream;
-// xn = norm_w * dtype(h32 * rsqrt(mean(h32^2) + eps)) -> write-through.  rmsnorm_rows_kernel's arithmetic (canonical sum of
-// squares, ls_common.h), the split sum of skinny_gemm_kernel's last arriver.
-// T threads per row: a workgroup handles 256 / T rows side by side (row0 + tid / T; rows >= M idle along).
-template <typename E, int T>
-__device__ __forceinline__ void tail_norm_row(const TailK& p, int S, int row0, const char* norm_w, char* smem, int tid_wg) {
-    using V8 = typename E::V8;
-    constexpr int NCH = 8192 / (8 * T);                      // hidden <= 8192
-    const int hidden = p.hidden;
-    const int tid = tid_wg % T;
-    const int row_raw = row0 + tid_wg / T;
-    const bool live = row_raw < p.M;
-    const int row = live ? row_raw : p.M - 1;                // (an idle group recomputes the last row and stores nothing)
-    float* slab_s = reinterpret_cast<float*>(smem) + (tid_wg / T) * 128;      // hidden / 64 slab sums of this group's row
-    V8 h[NCH], w8[NCH];
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xn, 0, p.M * hidden * 2, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int i = (c * T + tid) * 8;
-        float s8 = 0.f;
-        if (i < hidden) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
-            for (int s = 0; s < S; ++s) {
-                const float* src = p.part + ((long)s * TAIL_MP + row) * hidden + i;
-                a += *reinterpret_cast<const f32x4*>(src);
-                b += *reinterpret_cast<const f32x4*>(src + 4);
-            }
-            const V8 r = *reinterpret_cast<const V8*>(p.resid + ((long)row * p.ld_res + i) * 2);
-            w8[c] = *reinterpret_cast<const V8*>(norm_w + (long)i * 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[c][e] = E::from_f32(E::to_f32(r[e]) + round_to<E>(a[e]));
-                h[c][4 + e] = E::from_f32(E::to_f32(r[4 + e]) + round_to<E>(b[e]));
-            }
-            if (live) *reinterpret_cast<V8*>(p.resid + ((long)row * p.ld_res + i) * 2) = h[c];
-            s8 = ssq_quad(E::to_f32(h[c][0]), E::to_f32(h[c][1]), E::to_f32(h[c][2]), E::to_f32(h[c][3])) +
-                 ssq_quad(E::to_f32(h[c][4]), E::to_f32(h[c][5]), E::to_f32(h[c][6]), E::to_f32(h[c][7]));
-        }
-        const float tile = s8 + __shfl_xor(s8, 1);
-        const int b8 = (tid & 63) & ~7;
-        const float slab = ssq_slab64(__shfl(tile, b8), __shfl(tile, b8 + 2), __shfl(tile, b8 + 4), __shfl(tile, b8 + 6));
-        if ((tid & 7) == 0 && i < hidden) slab_s[i >> 6] = slab;
-    }
-    __syncthreads();
-    const float tot = ssq_row(slab_s, hidden >> 6);
-    const float rs = rsqrtf(tot / (float)hidden + p.eps);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int i = (c * T + tid) * 8;
-        if (i < hidden && live) {
-            V8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float n = round_to<E>(E::to_f32(h[c][e]) * rs);
-                o[e] = E::from_f32(E::to_f32(w8[c][e]) * n);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), xr, (unsigned)(((long)row * hidden + i) * 2), 0, 16);
-        }
-    }
-    __syncthreads();                                         // slab_s is the x staging area of the next projection
-}
-
-template <typename E, int MT, bool GU8>
-__global__ __launch_bounds__(GEMM_THREADS, 1) void layer_tail_kernel(const TailK p) {
-    using V8 = typename E::V8;
-    using V4 = typename E::V4;
-    using C4 = TailCore<E, MT, 4, 2>;
-    using CG = TailCore<E, MT, GU8 ? 8 : 4, GU8 ? 1 : 2>;
-    constexpr int NTG = GU8 ? 8 : 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int wg = blockIdx.x, G = p.G;
-    // (read before this workgroup's first arrival: see the header comment)
-    const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const unsigned target = (gen + 1u) * (unsigned)G;
-    V8 pool[32];
-    char* xlds = smem + wave * C4::XSLAB;
-    float* red = reinterpret_cast<float*>(smem);
-    // N1 / N2: the last ceil(M / R) workgroups normalise R rows each (R = p.n1_rows / p.n2_rows in {1, 2, 4}: with more rows
-    // per workgroup the phase fits into the workgroups that have no item of the projection behind it)
-    const int n1_wgs = (p.M + p.n1_rows - 1) / p.n1_rows, n2_wgs = (p.M + p.n2_rows - 1) / p.n2_rows;
-    const bool norm1_wg = wg >= G - n1_wgs, norm2_wg = wg >= G - n2_wgs;
-    auto norm_rows = [&](int S, int rows_per_wg, int first_wg, const char* nw) {
-        const int row0 = (wg - first_wg) * rows_per_wg;
-        tail_norm_row<E, 256>(p, S, row0, nw, smem, tid);
-    };
-    typedef __attribute__((address_space(3))) char lds_char_t;
-    const unsigned l2_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_char_t*)(smem + p.l2_scratch_off));
-
-    // the 4 waves' accumulators of 4 tiles -> LDS -> wave w sums tile 4h + w (plain) or the pair 4h + 2w, 4h + 2w + 1 (waves 0, 1)
-    auto reduce_plain = [&](const f32x4 (&acc)[4][MT], f32x4 (&r)[MT]) {
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(red + (((wave * 4 + t) * MT + mt) * 64 + lane) * 4) = acc[t][mt];
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + wave) * MT + mt) * 64 + lane) * 4);
-#pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + (((w2 * 4 + wave) * MT + mt) * 64 + lane) * 4);
-            r[mt] = v;
-        }
-    };
-    // a split-K projection whose partials go to p.part row-major (P1, P3)
-    auto partial_phase = [&](const TailW& w, const char* x, long ldx, bool first_prefetched) {
-        const int n_items = w.nslabs * w.S;
-        const __amdgpu_buffer_rsrc_t pr = part_rsrc(p.part, w.S * TAIL_MP * w.N * 4);
-        bool pre = first_prefetched;
-        for (int item = wg; item < n_items; item += G) {
-            const int slab = item % w.nslabs, split = item / w.nslabs;
-            typename C4::Geo g;
-            C4::geo(w, false, slab, split, wave, lane, g);
-            f32x4 acc[4][MT];
-            C4::mainloop(pool, g, x, ldx, p.M, xlds, acc, pre, lane);
-            pre = false;
-            f32x4 r[MT];
-            reduce_plain(acc, r);
-            const int nn = g.n_tile0 + wave * 16 + g4 * 4;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mt * 16 + l15;
-                if (m < p.M && nn < g.n_lim) st_coherent4(pr, (unsigned)((((long)split * TAIL_MP + m) * w.N + nn) * 4), r[mt]);
-            }
-            __syncthreads();                                 // `red` is the next item's x staging area
-        }
-    };
-
-    // ---------------- P1: o_proj ----------------
-    TAIL_STAMP(0);
-    partial_phase(p.o, p.attn, p.ld_attn, false);
-    TAIL_STAMP(1);
-    tail_arrive(p.sync, 0);
-    TAIL_STAMP(2);
-    // ---------------- N1 ----------------
-    typename CG::Geo gg;
-    bool pre_g = false;
-    auto prefetch_gu = [&]() {
-        if (wg < p.gu.nslabs) {
-            CG::geo(p.gu, true, wg, 0, wave, lane, gg);
-            CG::prefetch(pool, gg);
-            CG::prefetch_l2(gg, wave, gg.quarter, l2_scratch, p.l2_units * (GU8 ? 2 : 1));      // (one-k-step units are half as large)
-            pre_g = true;
-        }
-    };
-    if (norm1_wg) {
-        tail_wait(p.sync, 0, target, p.spin_limit, wave, lane);
-        TAIL_STAMP(3);
-        norm_rows(p.o.S, p.n1_rows, G - n1_wgs, p.norm1_w);
-        tail_arrive(p.sync, 1);
-        TAIL_STAMP(4);
-        prefetch_gu();
-    } else {
-        tail_arrive(p.sync, 1);                              // nothing to publish: counted in before the requests below
-        prefetch_gu();
-    }
-    // ---------------- P2: gate|up + SiLU ----------------
-    {
-        tail_wait(p.sync, 1, target, p.spin_limit, wave, lane);
-        TAIL_STAMP(5);
-        for (int item = wg; item < p.gu.nslabs; item += G) {
-            if (!pre_g) CG::geo(p.gu, true, item, 0, wave, lane, gg);
-            f32x4 acc[NTG][MT];
-            CG::mainloop(pool, gg, p.xn, p.hidden, p.M, xlds, acc, pre_g, lane);
-            pre_g = false;
-#pragma unroll
-            for (int h = 0; h < NTG / 4; ++h) {
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        *reinterpret_cast<f32x4*>(red + (((wave * 4 + t) * MT + mt) * 64 + lane) * 4) = acc[h * 4 + t][mt];
-                __syncthreads();
-                if (wave < 2) {
-                    const int nn = gg.n_tile0 + (h * 2 + wave) * 16 + g4 * 4;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4 gv = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + 2 * wave) * MT + mt) * 64 + lane) * 4);
-                        f32x4 uv = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + 2 * wave + 1) * MT + mt) * 64 + lane) * 4);
-#pragma unroll
-                        for (int w2 = 1; w2 < 4; ++w2) {
-                            gv += *reinterpret_cast<const f32x4*>(red + (((w2 * 4 + 2 * wave) * MT + mt) * 64 + lane) * 4);
-                            uv += *reinterpret_cast<const f32x4*>(red + (((w2 * 4 + 2 * wave + 1) * MT + mt) * 64 + lane) * 4);
-                        }
-                        const int m = mt * 16 + l15;
-                        V4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gt = round_to<E>(gv[e]);
-                            const float up = round_to<E>(uv[e]);
-                            const float sg = round_to<E>(gt / (1.0f + expf(-gt)));
-                            o[e] = E::from_f32(sg * up);
-                        }
-                        if (m < p.M && nn < gg.n_lim)
-                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.act + ((long)m * p.inter + nn) * 2),
-                                               __builtin_bit_cast(unsigned long long, o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        TAIL_STAMP(6);
-        tail_arrive(p.sync, 2);
-        TAIL_STAMP(7);
-    }
-    // ---------------- P3: down_proj ----------------
-    {
-        typename C4::Geo g3;
-        bool pre3 = false;
-        if (wg < p.down.nslabs * p.down.S) {
-            C4::geo(p.down, false, wg % p.down.nslabs, wg / p.down.nslabs, wave, lane, g3);
-            C4::prefetch(pool, g3);
-            C4::prefetch_l2(g3, wave, g3.quarter, l2_scratch, p.l2_units);
-            pre3 = true;
-        }
-        tail_wait(p.sync, 2, target, p.spin_limit, wave, lane);
-        TAIL_STAMP(8);
-        partial_phase(p.down, p.act, p.inter, pre3);
-        TAIL_STAMP(9);
-        tail_arrive(p.sync, 3);
-        TAIL_STAMP(10);
-    }
-    // ---------------- N2 (+ P4's first requests) ----------------
-    const bool has_q = p.qkv != nullptr;
-    typename C4::Geo g4q;
-    bool pre4 = false;
-    auto prefetch_q = [&]() {
-        if (has_q && wg < p.q.nslabs * p.q.S) {
-            C4::geo(p.q, false, wg % p.q.nslabs, wg / p.q.nslabs, wave, lane, g4q);
-            C4::prefetch(pool, g4q);
-            C4::prefetch_l2(g4q, wave, g4q.quarter, l2_scratch, p.l2_units);
-            pre4 = true;
-        }
-    };
-    if (norm2_wg) {
-        tail_wait(p.sync, 3, target, p.spin_limit, wave, lane);
-        TAIL_STAMP(11);
-        norm_rows(p.down.S, p.n2_rows, G - n2_wgs, p.norm2_w);
-        tail_arrive(p.sync, 4);
-        TAIL_STAMP(12);
-        prefetch_q();
-    } else {
-        tail_arrive(p.sync, 4);
-        prefetch_q();
-    }
-    // ---------------- P4: the next layer's q|k|v + RoPE ----------------
-    if (has_q) {
-        tail_wait(p.sync, 4, target, p.spin_limit, wave, lane);
-        TAIL_STAMP(13);
-        const TailW& w = p.q;
-        const int n_items = w.nslabs * w.S;
-        constexpr int TILE_F = MT * 4 * 64;
-        for (int item = wg; item < n_items; item += G) {
-            const int slab = item % w.nslabs, split = item / w.nslabs;
-            if (!pre4) C4::geo(w, false, slab, split, wave, lane, g4q);
-            f32x4 acc[4][MT];
-            C4::mainloop(pool, g4q, p.xn, p.hidden, p.M, xlds, acc, pre4, lane);
-            pre4 = false;
-            // waves 0, 1 finish the tile pair (2w, 2w + 1): a rotary pair (ls_linear_pack_rope)
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(red + (((wave * 4 + t) * MT + mt) * 64 + lane) * 4) = acc[t][mt];
-            __syncthreads();
-            const bool finisher = wave < 2;
-            f32x4 r[2][MT];
-            if (finisher) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + 2 * wave + q) * MT + mt) * 64 + lane) * 4);
-#pragma unroll
-                        for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(red + (((w2 * 4 + 2 * wave + q) * MT + mt) * 64 + lane) * 4);
-                        r[q][mt] = v;
-                    }
-            }
-            bool last = true;
-            if (w.S > 1) {
-                if (finisher) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const __amdgpu_buffer_rsrc_t mine = part_rsrc(p.qkv_part + (((long)split * w.nslabs + slab) * 4 + 2 * wave + q) * TILE_F, TILE_F * 4);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) st_coherent4(mine, (mt * 64 + lane) * 16, r[q][mt]);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                volatile unsigned& s_last = *reinterpret_cast<volatile unsigned*>(smem + p.flag_off);
-                if (tid == 0) {
-                    const unsigned prev = __hip_atomic_fetch_add(p.qkv_counters + slab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_last = (prev == (unsigned)w.S - 1u);
-                    if (prev == (unsigned)w.S - 1u) __hip_atomic_store(p.qkv_counters + slab, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                last = s_last != 0u;
-                if (last && finisher) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) r[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int s = 0; s < w.S; ++s)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const __amdgpu_buffer_rsrc_t src = part_rsrc(p.qkv_part + (((long)s * w.nslabs + slab) * 4 + 2 * wave + q) * TILE_F, TILE_F * 4);
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) r[q][mt] += ld_coherent4(src, (mt * 64 + lane) * 16);
-                        }
-                }
-            }
-            if (last && finisher) {                          // EPI_QKV_ROPE of skinny_gemm_kernel
-                const int tl = ((g4q.n_tile0 - g4q.seg_base) >> 4) + wave * 2;
-                const bool rot = g4q.seg < p.rope_segs;
-                const int d = ((tl & 7) >> 1) * 16 + g4 * 4;
-                const int n_lo = rot ? g4q.seg_base + (tl >> 3) * 128 + d : g4q.seg_base + tl * 16 + g4 * 4;
-                const int n_hi = rot ? n_lo + 64 : n_lo + 16;
-                float bl[4] = {0.f, 0.f, 0.f, 0.f}, bh[4] = {0.f, 0.f, 0.f, 0.f};
-                if (g4q.bias_p != nullptr) {
-                    if (n_lo < g4q.n_lim) {
-                        const V4 b4 = *reinterpret_cast<const V4*>(g4q.bias_p + (long)n_lo * 2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bl[e] = E::to_f32(b4[e]);
-                    }
-                    if (n_hi < g4q.n_lim) {
-                        const V4 b4 = *reinterpret_cast<const V4*>(g4q.bias_p + (long)n_hi * 2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bh[e] = E::to_f32(b4[e]);
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int m = mt * 16 + l15;
-                    if (m >= p.M) continue;
-                    V4 lo, hi;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        lo[e] = E::from_f32(r[0][mt][e] + bl[e]);
-                        hi[e] = E::from_f32(r[1][mt][e] + bh[e]);
-                    }
-                    if (rot) {
-                        const V4 cl = *reinterpret_cast<const V4*>(p.rope_cos + ((long)m * 128 + d) * 2);
-                        const V4 ch = *reinterpret_cast<const V4*>(p.rope_cos + ((long)m * 128 + 64 + d) * 2);
-                        const V4 sl = *reinterpret_cast<const V4*>(p.rope_sin + ((long)m * 128 + d) * 2);
-                        const V4 sh = *reinterpret_cast<const V4*>(p.rope_sin + ((long)m * 128 + 64 + d) * 2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float xl = E::to_f32(lo[e]), xh = E::to_f32(hi[e]);
-                            lo[e] = E::from_f32(round_to<E>(xl * E::to_f32(cl[e])) + round_to<E>(-xh * E::to_f32(sl[e])));
-                            hi[e] = E::from_f32(round_to<E>(xh * E::to_f32(ch[e])) + round_to<E>(xl * E::to_f32(sh[e])));
-                        }
-                    }
-                    if (n_lo < g4q.n_lim) *reinterpret_cast<V4*>(p.qkv + ((long)m * p.ld_qkv + n_lo) * 2) = lo;
-                    if (n_hi < g4q.n_lim) *reinterpret_cast<V4*>(p.qkv + ((long)m * p.ld_qkv + n_hi) * 2) = hi;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    TAIL_STAMP(14);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA request of this wave outlives it (a no-op here: the main loops waited)
-    // the generation moves on: every workgroup has read it (this workgroup's waits above needed all G arrivals at C2)
-    if (wg == 0 && tid == 0) __hip_atomic_store(p.sync, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---- weight packing ---------------------------------------------------------------------
 // The 64 rows of slab g at k-step s form one contiguous 4 KB block of 4 tiles:
@@ -1324,103 +690,11 @@ int launch_mt4(const GemmK& k, const Plan& pl, hipStream_t s) {      // epilogue
     }
 }
 
-// ---- layer tail: plans + launch ------------------------------------------------------------------------------------------
-struct TailPlan {
-    Plan o, gu, down, q;
-    bool has_q;
-    size_t off_counters, off_act, off_part, off_qpart, total;
-    int G;
-    size_t lds;
-};
-
-static int tail_fill(const Plan& pl, const void* const* w, const void* const* bias, const int* n, int n_seg, int K, TailW& t) {
-    for (int i = 0; i < 3; ++i) {
-        t.w[i] = i < n_seg ? static_cast<const char*>(w[i]) : nullptr;
-        t.bias[i] = (i < n_seg && bias) ? static_cast<const char*>(bias[i]) : nullptr;
-        t.n[i] = i < n_seg ? n[i] : 0;
-    }
-    t.K = K;
-    t.nks = pl.nks;
-    t.N = pl.N;
-    t.nslabs = pl.nslabs;
-    t.S = pl.S;
-    t.NT = pl.NT;
-    return LS_OK;
-}
-
-static int tail_plan(const ls_layer_tail_desc* d, TailPlan& tp) {
-    if (!d || !d->attn || !d->resid || !d->xn || !d->w_o || !d->w_gate_up || !d->w_down || !d->norm1_weight || !d->norm2_weight)
-        LS_FAIL(LS_ERR_INVALID_ARG, "ls_layer_tail: null pointer");
-    if (d->dtype != LS_F16 && d->dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "ls_layer_tail: dtype");
-    if (d->M < 33 || d->M > 80) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: M=%d (33..80 token rows: the verification pass)", d->M);
-    if (d->hidden < 128 || d->hidden % 64 != 0 || d->hidden > 8192) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: hidden=%d", d->hidden);
-    if (d->inter % 64 != 0 || d->Ko % 64 != 0) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: inter=%d Ko=%d must be multiples of 64", d->inter, d->Ko);
-    // each projection's plan is the stand-alone launch's (make_plan on the descriptor ls_linear_fwd would get): same split
-    // count, same slab height -- the summation order of every output is the one of the eight-launch chain
-    ls_linear_desc l{};
-    char dummy = 0;
-    l.x = &dummy; l.y = &dummy;
-    l.M = d->M; l.dtype = d->dtype; l.n_splits = 0;
-    l.w[0] = d->w_o; l.n[0] = d->hidden; l.n_seg = 1; l.K = d->Ko; l.ldx = d->Ko; l.ldy = d->hidden; l.epilogue = LS_EPI_NONE;
-    int rc = make_plan(&l, tp.o);
-    if (rc) return rc;
-    l.w[0] = d->w_gate_up; l.n[0] = d->inter; l.K = d->hidden; l.ldx = d->hidden; l.ldy = d->inter; l.epilogue = LS_EPI_SILU_MUL;
-    rc = make_plan(&l, tp.gu);
-    if (rc) return rc;
-    l.w[0] = d->w_down; l.n[0] = d->hidden; l.K = d->inter; l.ldx = d->inter; l.ldy = d->hidden; l.epilogue = LS_EPI_NONE;
-    rc = make_plan(&l, tp.down);
-    if (rc) return rc;
-    if (tp.o.NT != 4 || tp.down.NT != 4) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: o_proj / down_proj plans with 128-row slabs");
-    if (tp.gu.S != 1) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: gate|up of %d columns would be split in K", d->inter);
-    tp.has_q = d->n_qkv_seg > 0;
-    int nq = 0;
-    if (tp.has_q) {
-        if (d->n_qkv_seg > 3 || !d->qkv || !d->rope_cos || !d->rope_sin) LS_FAIL(LS_ERR_INVALID_ARG, "ls_layer_tail: q|k|v arguments");
-        for (int i = 0; i < d->n_qkv_seg; ++i) {
-            l.w[i] = d->w_qkv[i]; l.n[i] = d->n_qkv[i]; l.bias[i] = d->b_qkv[i];
-            nq += d->n_qkv[i];
-        }
-        l.n_seg = d->n_qkv_seg; l.K = d->hidden; l.ldx = d->hidden; l.ldy = nq; l.epilogue = LS_EPI_QKV_ROPE;
-        l.rope_cos = d->rope_cos; l.rope_sin = d->rope_sin;
-        rc = make_plan(&l, tp.q);
-        if (rc) return rc;
-        if (d->ld_qkv < nq || (d->ld_qkv % 4) != 0) LS_FAIL(LS_ERR_INVALID_ARG, "ls_layer_tail: ld_qkv");
-    }
-    tp.G = num_cus_gemm();
-    if (tp.G < d->M) LS_FAIL(LS_ERR_UNSUPPORTED, "ls_layer_tail: fewer compute units (%d) than token rows", tp.G);
-    const int maxS = tp.o.S > tp.down.S ? tp.o.S : tp.down.S;
-    size_t off = (size_t)TAIL_SYNC_WORDS * 4;
-    off = (off + 255) & ~(size_t)255;
-    tp.off_counters = off;
-    off += COUNTER_BYTES;
-    tp.off_act = off;
-    off += ((size_t)d->M * d->inter * 2 + 255) & ~(size_t)255;
-    tp.off_part = off;
-    off += (size_t)maxS * TAIL_MP * d->hidden * 4;
-    tp.off_qpart = off;
-    off += tp.has_q ? tp.q.part_bytes : 0;
-#ifdef LS_TAIL_PROF
-    off = (off + 255) & ~(size_t)255;
-    off += (size_t)tp.G * 16 * 8;                            // the stamps are the LAST G * 128 bytes of the workspace
+#ifdef LS_WITH_TAIL
+#define LS_TAIL_PART 2
+#include "../../tools/mb/layer_tail_kernel.inc"
+#undef LS_TAIL_PART
 #endif
-    tp.total = off;
-    tp.lds = (size_t)16 * 4 * 5 * 64 * 4 + 16 + 1024;        // as the MT = 5 stand-alone launch (4 waves x 4 tiles x 5 accumulators + the flag) + the DMA scratch slot
-    return LS_OK;
-}
-
-template <typename E>
-static int tail_launch(const TailK& k, const TailPlan& tp, hipStream_t s) {
-    const bool gu8 = tp.gu.NT == 8;
-    auto kern = gu8 ? layer_tail_kernel<E, 5, true> : layer_tail_kernel<E, 5, false>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[gu8]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done[gu8] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tp.G), dim3(GEMM_THREADS), tp.lds, s, k);
-    LS_CHECK_LAUNCH("layer_tail_kernel");
-    return LS_OK;
-}
 
 }  // namespace
 
@@ -1527,89 +801,10 @@ int ls_linear_prefetch(const ls_linear_desc* d, int units, void* workspace, size
     return linear_launch(d, workspace, workspace_bytes, stream, units);
 }
 
-size_t ls_layer_tail_workspace_bytes(const ls_layer_tail_desc* d) {
-    TailPlan tp;
-    if (tail_plan(d, tp) != LS_OK) return 0;
-    return tp.total;
-}
-
-int ls_layer_tail_fwd(const ls_layer_tail_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
-    TailPlan tp;
-    int rc = tail_plan(d, tp);
-    if (rc) return rc;
-    if (!workspace || workspace_bytes < tp.total) LS_FAIL(LS_ERR_WORKSPACE, "ls_layer_tail_fwd: workspace %zu < %zu bytes", workspace_bytes, tp.total);
-    char* ws = static_cast<char*>(workspace);
-    TailK k{};
-    k.M = d->M;
-    k.G = tp.G;
-    k.attn = static_cast<const char*>(d->attn);
-    k.ld_attn = d->ld_attn;
-    k.resid = static_cast<char*>(d->resid);
-    k.ld_res = d->ld_res;
-    k.xn = static_cast<char*>(d->xn);
-    k.act = ws + tp.off_act;
-    k.part = reinterpret_cast<float*>(ws + tp.off_part);
-    k.qkv = tp.has_q ? static_cast<char*>(d->qkv) : nullptr;
-    k.ld_qkv = d->ld_qkv;
-    k.qkv_part = reinterpret_cast<float*>(ws + tp.off_qpart);
-    k.qkv_counters = reinterpret_cast<unsigned*>(ws + tp.off_counters);
-    k.norm1_w = static_cast<const char*>(d->norm1_weight);
-    k.norm2_w = static_cast<const char*>(d->norm2_weight);
-    k.eps = d->norm_eps;
-    k.rope_cos = static_cast<const char*>(d->rope_cos);
-    k.rope_sin = static_cast<const char*>(d->rope_sin);
-    k.rope_segs = d->n_qkv_seg < 2 ? d->n_qkv_seg : 2;
-    k.hidden = d->hidden;
-    k.inter = d->inter;
-    const void* wo[3] = {d->w_o, nullptr, nullptr};
-    const void* wg[3] = {d->w_gate_up, nullptr, nullptr};
-    const void* wd[3] = {d->w_down, nullptr, nullptr};
-    const int no[3] = {d->hidden, 0, 0}, ng[3] = {d->inter, 0, 0};
-    tail_fill(tp.o, wo, nullptr, no, 1, d->Ko, k.o);
-    tail_fill(tp.gu, wg, nullptr, ng, 1, d->hidden, k.gu);
-    tail_fill(tp.down, wd, nullptr, no, 1, d->inter, k.down);
-    if (tp.has_q) tail_fill(tp.q, d->w_qkv, d->b_qkv, d->n_qkv, d->n_qkv_seg, d->hidden, k.q);
-    k.sync = reinterpret_cast<unsigned*>(ws);
-    k.spin_limit = 1u << 19;
-    k.flag_off = (int)tp.lds - 16 - 1024;
-    k.l2_scratch_off = (int)tp.lds - 1024;
-    {
-        // Seam-time L2 prefetch: measured NEGATIVE (profiles/r4_tail_timeline_l2_*.json: 4 units = 32 KB per wave make the
-        // norm phases -- the critical path of a seam -- twice as long, 5.5 -> 11 us: their partial reads queue behind 25 MB of
-        // other workgroups' prefetch; the launch goes 126 -> 128.5 us, with 8 units 137).  Off; LS_TAIL_L2_UNITS re-enables it.
-        static int l2u = -1;
-        if (l2u < 0) {
-            const char* e = getenv("LS_TAIL_L2_UNITS");
-            l2u = e ? atoi(e) : 0;
-            if (l2u < 0 || l2u > 16) l2u = 0;
-        }
-        k.l2_units = l2u;
-        // rows per norm workgroup: the smallest of 1, 2, 4 that fits the phase into the workgroups WITHOUT an item of the
-        // projection behind it (a norm workgroup starts that projection late: no requests in flight while it normalises)
-        // One row per norm workgroup.  Two or four rows side by side (so that the phase fits into the workgroups without an
-        // item of the projection behind it) were measured: the phase is bound by what ONE compute unit pulls of the
-        // write-through partials -- 5.5 us for one row, 10 for two, 19 for four (profiles/r4_tail_timeline_rows_*.json).
-        k.n1_rows = 1;
-        k.n2_rows = 1;
-    }
-    k.prof = nullptr;
-#ifdef LS_TAIL_PROF
-    k.prof = reinterpret_cast<unsigned long long*>(ws + tp.total - (size_t)tp.G * 16 * 8);
+#ifdef LS_WITH_TAIL
+#define LS_TAIL_PART 3
+#include "../../tools/mb/layer_tail_kernel.inc"
+#undef LS_TAIL_PART
 #endif
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (d->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_start), s);
-    rc = d->dtype == LS_F16 ? tail_launch<ElemF16>(k, tp, s) : tail_launch<ElemBF16>(k, tp, s);
-    if (d->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(d->ev_stop), s);
-    return rc;
-}
-
-int ls_layer_tail_status(const void* workspace) {
-    // synchronises; reads the error latch (a wait inside a launch gave up: results since then are invalid)
-    unsigned v[2] = {0, 0};
-    if (!workspace) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(v, workspace, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)v[1];
-}
 
 }  // extern "C"

@@ -313,15 +313,11 @@ class LlamaAttention(nn.Module):
         q, k, v = self._qkv(hidden_states, position_embeddings)
         return self.tree_attend(q, k, v, cache_lens, tree_mask, tree_mask_bits, hidden_states.dtype)
 
-    def tree_attend(self, q, k, v, cache_lens, tree_mask=None, tree_mask_bits=None, dtype=None, project=True):
-        """The attention of ``tree_decoding`` on projected, rotated q/k/v [bsz, q_len, heads, 128] (+ o_proj unless
-        ``project`` is False: the fused layer tail of ``LlamaModel`` applies it)."""
+    def tree_attend(self, q, k, v, cache_lens, tree_mask=None, tree_mask_bits=None, dtype=None):
+        """The attention of ``tree_decoding`` on projected, rotated q/k/v [bsz, q_len, heads, 128], then o_proj."""
         bsz, q_len = q.shape[0], q.shape[1]
         hidden_states = SimpleNamespace(dtype=dtype if dtype is not None else q.dtype)
-        if not project:
-            o_proj = lambda a: a
-        else:
-            o_proj = self.o_proj
+        o_proj = self.o_proj
         if tree_mask is None and tree_mask_bits is None:
             assert q_len == 1, "You are in the first step of tree decoding, thus you should not input qlen > 2 without tree mask"
             attn = self.ops.kvcache_attention(q, self.K_Cache, self.V_Cache, k, v, cache_seqlens=cache_lens, causal=True,
@@ -409,15 +405,11 @@ class LlamaModel(nn.Module):
                 position_ids = self.ops.tree_positions(tree_mask, cache_lens)
         if tree_mask is not None and tree_mask_bits is None:
             tree_mask_bits = self.ops.pack_tree_mask(tree_mask)     # once per pass, shared by all layers
-        inputs_embeds_own = inputs_embeds is None                  # rows this pass may overwrite (the fused tail updates them in place)
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         hidden_states = inputs_embeds
         if position_embeddings is None:
             position_embeddings = self.rotary_emb(hidden_states, position_ids)
-        if self._tail_ok(hidden_states, exec_type, tree_mask_bits, shard):
-            out = self._forward_tail(hidden_states, position_embeddings, cache_lens, tree_mask_bits, own_rows=inputs_embeds_own)
-            return SimpleNamespace(last_hidden_state=out, past_key_values=None)
         residual = None                                            # every `residual + mlp(x)` rides in the next norm kernel
         for decoder_layer in self.layers:
             hidden_states, residual = decoder_layer(hidden_states, position_embeddings, cache_lens, flex_attn, exec_type,
@@ -425,63 +417,6 @@ class LlamaModel(nn.Module):
                                                     pending_residual=residual, defer_residual=True)
         hidden_states, _ = self.norm(hidden_states, residual=residual)
         return SimpleNamespace(last_hidden_state=hidden_states, past_key_values=None)
-
-    # ---- the verification pass with ONE launch between two attention calls (ops.layer_tail, round 4) ----------------------
-    def _tail_ok(self, hidden_states, exec_type, tree_mask_bits, shard) -> bool:
-        """The fused path takes the 74-row verification pass of an unsharded model whose projections all stream (no biases
-        on o_proj / the MLP: Llama and Qwen2).  Everything else -- other passes, CPU operator sets, sharded KV (its attention
-        call is three launches with a peer exchange, and two ranks on one GPU could not keep two persistent launches resident)
-        -- takes the layer-by-layer path below; both compute the same bits (tests/test_gpu_tail.py)."""
-        ops = self.ops
-        if exec_type != "tree_decoding" or tree_mask_bits is None or shard is not None or not hasattr(ops, "layer_tail"):
-            return False
-        if not hidden_states.is_cuda or not FUSE_QKV_ROPE:
-            return False
-        rows = hidden_states.shape[0] * hidden_states.shape[1]
-        l0 = self.layers[0]
-        a, m = l0.self_attn, l0.mlp
-        if a.head_dim != 128 or a.o_proj.bias is not None or m.gate_proj.bias is not None or m.down_proj.bias is not None:
-            return False
-        if any(pr.out_features % 128 for pr in (a.q_proj, a.k_proj, a.v_proj)):
-            return False
-        return ops.layer_tail_supported(rows, self.config.hidden_size, m.gate_proj.out_features, hidden_states.dtype,
-                                        Ko=a.o_proj.in_features, n_qkv=(a.q_proj.out_features, a.k_proj.out_features, a.v_proj.out_features))
-
-    def _forward_tail(self, hidden_states, position_embeddings, cache_lens, tree_mask_bits, own_rows=True):
-        ops = self.ops
-        bsz, q_len, hid = hidden_states.shape
-        M = bsz * q_len
-        cos, sin = position_embeddings
-        cos2, sin2 = cos.reshape(M, -1), sin.reshape(M, -1)
-        resid = hidden_states.reshape(M, hid)
-        if not own_rows or not resid.is_contiguous():
-            resid = resid.contiguous().clone()                     # the residual stream is updated in place
-        l0 = self.layers[0]
-        x = l0.input_layernorm(resid.view(bsz, q_len, hid))
-        q, k, v = l0.self_attn._qkv(x, position_embeddings)
-        xn = None
-        n = len(self.layers)
-        for i, layer in enumerate(self.layers):
-            att = layer.self_attn
-            attn = att.tree_attend(q, k, v, cache_lens, None, tree_mask_bits, hidden_states.dtype, project=False)
-            nxt = self.layers[i + 1] if i + 1 < n else None
-            if nxt is not None:
-                na = nxt.self_attn
-                projs = (na.q_proj, na.k_proj, na.v_proj)
-                xn, qkv = ops.layer_tail(attn.reshape(M, -1), resid, att.o_proj.packed(), layer.post_attention_layernorm.weight,
-                                         layer.mlp._packed_gate_up(), layer.mlp.down_proj.packed(), nxt.input_layernorm.weight,
-                                         layer.post_attention_layernorm.variance_epsilon,
-                                         qkv_weights=[pr.packed(rope=j < 2) for j, pr in enumerate(projs)],
-                                         qkv_biases=[pr.bias for pr in projs], cos=cos2, sin=sin2)
-                nq, nk = na.q_proj.out_features, na.k_proj.out_features
-                q = qkv[:, :nq].view(bsz, q_len, na.num_heads, na.head_dim)
-                k = qkv[:, nq:nq + nk].view(bsz, q_len, na.num_key_value_heads, na.head_dim)
-                v = qkv[:, nq + nk:].view(bsz, q_len, na.num_key_value_heads, na.head_dim)
-            else:
-                xn, _ = ops.layer_tail(attn.reshape(M, -1), resid, att.o_proj.packed(), layer.post_attention_layernorm.weight,
-                                       layer.mlp._packed_gate_up(), layer.mlp.down_proj.packed(), self.norm.weight,
-                                       layer.post_attention_layernorm.variance_epsilon)
-        return xn.view(bsz, q_len, hid)
 
     def set_kv_len_hint(self, hint: Optional[int]):
         for layer in self.layers:

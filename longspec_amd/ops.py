@@ -96,7 +96,7 @@ _gemm_ws = _ZeroedWorkspace()
 
 def workspace_tensors():
     """The scratch buffers currently handed out (a captured HIP graph keeps them alive: it holds their addresses)."""
-    return list(_ws._buf.values()) + list(_gemm_ws._buf.values()) + list(_tail_ws.values())
+    return list(_ws._buf.values()) + list(_gemm_ws._buf.values())
 
 
 _linear_need = {}            # (shape key) -> workspace bytes of the launch plan
@@ -396,126 +396,6 @@ def mlp_gate_up(x: torch.Tensor, gate_up: PackedWeight, n_splits: int = 0, timin
     activation are rounded to the storage dtype before the product (qwen2.py:229).  ``gate_up`` = pack_gate_up(...)."""
     y = _linear_call(x, [gate_up], None, _C.LS_EPI_SILU_MUL, n_splits, timing, norm=norm)
     return y.view(*x.shape[:-1], gate_up.n)
-
-
-# ---- the persistent layer tail (one launch between two attention calls of a verification pass) -------------------------
-# Round-4 measurement (profiles/r4_tail_*.json, DESIGN 3.5): the persistent launch is bit-identical to the eight launches it
-# replaces and NOT faster -- 126-131 us per layer against ~128: each of its two norm seams costs ~12 us (two counter hops of
-# 2-3 us and a 5.5 us norm phase bound by one CU's pull of the write-through partials) where the launch chain pays ~15, and the
-# projections inside it stream no faster than the stand-alone launches.  Off by default; bench.py --layer-tail measures it.
-LAYER_TAIL = False
-_tail_ws = {}                # device index -> the DEDICATED, zero-initialised workspace (it carries the launch generation)
-_tail_need = {}
-_tail_timing = None
-
-
-def set_tail_timing(hook):
-    """Profiling: ``hook(weight_bytes) -> (start_event, stop_event) | None`` before every layer-tail launch (bench.py)."""
-    global _tail_timing
-    _tail_timing = hook
-
-
-_tail_plan_ok = {}
-
-
-def layer_tail_supported(rows: int, hidden: int, inter: int, dtype, Ko: Optional[int] = None, n_qkv=()) -> bool:
-    """Does ``ls_layer_tail_fwd`` take this chain (asked of the library's own planner, cached per shape)?"""
-    if not (LAYER_TAIL and dtype in _DT and 33 <= rows <= LINEAR_MAX_ROWS):
-        return False
-    key = (rows, hidden, inter, dtype, Ko, tuple(n_qkv))
-    ok = _tail_plan_ok.get(key)
-    if ok is None:
-        d = _C.LayerTailDesc()
-        one = 16                                                   # (any non-null address: the planner only looks at the shapes)
-        d.attn = d.resid = d.xn = d.w_o = d.w_gate_up = d.w_down = d.norm1_weight = d.norm2_weight = one
-        d.M, d.hidden, d.inter, d.Ko = rows, hidden, inter, Ko if Ko is not None else hidden
-        d.ld_attn, d.ld_res = d.Ko, hidden
-        d.dtype = _DT[dtype]
-        if n_qkv:
-            d.qkv = d.rope_cos = d.rope_sin = one
-            for i, n in enumerate(n_qkv):
-                d.w_qkv[i] = one
-                d.n_qkv[i] = n
-            d.n_qkv_seg = len(n_qkv)
-            d.ld_qkv = sum(n_qkv)
-        ok = _C.load().ls_layer_tail_workspace_bytes(C.byref(d)) != 0
-        _tail_plan_ok[key] = ok
-    return ok
-
-
-def layer_tail(attn: torch.Tensor, resid: torch.Tensor, w_o: PackedWeight, norm1_w: torch.Tensor, w_gate_up: PackedWeight,
-               w_down: PackedWeight, norm2_w: torch.Tensor, eps: float, qkv_weights=None, qkv_biases=None, cos=None, sin=None):
-    """Everything between the attention of layer i and the attention of layer i + 1 in ONE launch (include/longspec_hip.h,
-    ``ls_layer_tail_fwd``): ``resid`` [M, hidden] is updated IN PLACE to the residual stream behind the MLP; returns
-    ``(xn, qkv)`` -- ``xn`` = norm2(resid) [M, hidden], ``qkv`` = the next layer's rotated q|k|v projections [M, sum n] (None
-    when ``qkv_weights`` is None: the last layer, norm2 = the model's final norm).  Bit-identical to
-    ``linear -> rmsnorm(residual) -> mlp_gate_up -> linear -> rmsnorm(residual) -> linear_qkv_rope``."""
-    _dev(attn, resid, norm1_w, norm2_w, cos, sin)
-    M, Ko = attn.shape
-    hidden = resid.shape[1]
-    inter = w_gate_up.n
-    if attn.stride(1) != 1 or resid.stride(1) != 1 or not norm1_w.is_contiguous() or not norm2_w.is_contiguous():
-        raise ValueError("layer_tail: rows must be contiguous")
-    if w_o.k != Ko or w_o.n != hidden or w_gate_up.k != hidden or w_down.k != inter or w_down.n != hidden:
-        raise ValueError("layer_tail: weight shapes do not chain")
-    d = _C.LayerTailDesc()
-    d.attn, d.ld_attn = attn.data_ptr(), attn.stride(0)
-    d.resid, d.ld_res = resid.data_ptr(), resid.stride(0)
-    xn = torch.empty((M, hidden), dtype=attn.dtype, device=attn.device)
-    d.xn = xn.data_ptr()
-    d.w_o, d.w_gate_up, d.w_down = w_o.data.data_ptr(), w_gate_up.data.data_ptr(), w_down.data.data_ptr()
-    d.norm1_weight, d.norm2_weight = norm1_w.data_ptr(), norm2_w.data_ptr()
-    d.norm_eps = eps
-    d.M, d.hidden, d.inter, d.Ko = M, hidden, inter, Ko
-    d.dtype = _dtype(attn)
-    qkv = None
-    wbytes = (w_o.n * w_o.k + 2 * inter * hidden + w_down.n * w_down.k) * attn.element_size()
-    if qkv_weights is not None:
-        qkv_weights = list(qkv_weights)
-        nq = sum(w.n for w in qkv_weights)
-        qkv = torch.empty((M, nq), dtype=attn.dtype, device=attn.device)
-        for i, w in enumerate(qkv_weights):
-            if w.rope != (i < 2) or w.k != hidden:
-                raise ValueError("layer_tail: q, k packed with rope=True, v without; K = hidden")
-            d.w_qkv[i] = w.data.data_ptr()
-            b = qkv_biases[i] if qkv_biases is not None else None
-            d.b_qkv[i] = b.data_ptr() if b is not None else None
-            d.n_qkv[i] = w.n
-            wbytes += w.n * w.k * attn.element_size()
-        d.n_qkv_seg = len(qkv_weights)
-        d.qkv, d.ld_qkv = qkv.data_ptr(), nq
-        d.rope_cos, d.rope_sin = cos.data_ptr(), sin.data_ptr()
-    lib = _C.load()
-    key = (M, hidden, inter, Ko, d.dtype, tuple(d.n_qkv), d.n_qkv_seg)
-    need = _tail_need.get(key)
-    if need is None:
-        need = lib.ls_layer_tail_workspace_bytes(C.byref(d))
-        if need == 0:
-            _C.check(lib.ls_layer_tail_fwd(C.byref(d), None, 0, _stream()), "ls_layer_tail_fwd")      # raises with the reason
-        _tail_need[key] = need
-    ws = _tail_ws.get(attn.device.index)
-    if ws is None or ws.numel() < need:
-        if ws is not None:
-            torch.cuda.synchronize(attn.device)                # (launches of the old buffer are done before it is dropped)
-        ws = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=attn.device)
-        _tail_ws[attn.device.index] = ws
-    if _tail_timing is not None:
-        t = _tail_timing(wbytes)
-        if t is not None:
-            d.ev_start, d.ev_stop = t[0].cuda_event, t[1].cuda_event
-    _C.check(lib.ls_layer_tail_fwd(C.byref(d), ws.data_ptr(), ws.numel(), _stream()), "ls_layer_tail_fwd")
-    return xn, qkv
-
-
-def layer_tail_check(device=None):
-    """Reads the error latch of the layer-tail workspace (synchronises): raises when a launch gave up waiting for a
-    workgroup that was not resident -- every result since then is invalid."""
-    for idx, ws in _tail_ws.items():
-        if device is not None and device.index != idx:
-            continue
-        if _C.load().ls_layer_tail_status(ws.data_ptr()) != 0:
-            raise RuntimeError("ls_layer_tail: a wait inside a launch timed out (workgroups not co-resident: is another process "
-                               "using this GPU?); results since then are invalid.  Set longspec_amd.ops.LAYER_TAIL = False.")
 
 
 def causal_mask_bits(n: int, device) -> torch.Tensor:

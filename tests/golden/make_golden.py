@@ -451,10 +451,10 @@ def gen_stochastic_long(llama, llama_glide):
     # The reference's T > 0 loop raises in the round after one that accepted all gamma levels (llama_glide.py:1081), so a long
     # run needs a model that never does within its budget: candidates in order, the first that completes is the fixture.
     cands = [("t_long_mixed_s%d" % i, {}, 47 + i, ag, 720 + 10 * i, 160, [4, 16, 16, 16, 16], 0.8)
-             for i, ag in enumerate([0.05, 0.1, 0.1, 0.15, 0.15, 0.2, 0.2, 0.3])]
+             for i, ag in enumerate([0.05, 0.1, 0.1, 0.15, 0.15, 0.2, 0.2, 0.3, 0.3, 0.3])]
     runs = []
     for name, over, wseed, agree, plen, glen, shape, T in cands:
-        if runs:
+        if len(runs) >= 3:
             break
         cfg = toy.toy_config(**over)
         tgt, drf = toy.make_weights(cfg, wseed, agreement=agree)

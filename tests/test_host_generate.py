@@ -240,3 +240,24 @@ def test_spec_generate_with_temperature_matches_reference(run):
                                             max_gen_len=run["max_gen_len"], temperature=run["temperature"])
     assert (int(count), int(num)) == (run["count"], run["num"])
     assert torch.equal(out, run["out"])
+
+
+def test_trace_compare_accepts_the_oracle_run_without_near_ties():
+    """tests/trace_compare.py (the GPU long-run tests' "exact up to explained near-ties" comparison) on the CPU path: the host
+    logic on the oracle's operators reproduces every round's draft tree, target predictions and acceptance of the reference's
+    long run, so the comparison must find equal trees in every round -- and must reject a run whose tree was tampered with."""
+    import trace_compare
+    run = [r for r in RUNS_LONG if r["name"] == "long_gqa_s1"][0]
+    m = build(run)
+    spy = trace_compare.RoundSpy(oracle_ops)
+    m.ops = spy
+    m.tree_spec_generate(run["prompt"], torch.tensor([run["prompt_len"]]), tree_shape=run["tree_shape"],
+                         max_gen_len=run["max_gen_len"], eos_id=run["eos_id"])
+    st = trace_compare.compare(spy.rounds, run, run["cfg"].vocab_size, tol=0.02)
+    assert st["rounds_compared"] == run["tree_num"] - 1 and st["rounds_with_equal_trees"] == st["rounds_compared"], st
+    # a candidate that is NOT a near-tie must be rejected: replace one deep node's token in round 3
+    bad = [dict(r) for r in spy.rounds]
+    bad[3]["spec"] = bad[3]["spec"].clone()
+    bad[3]["spec"][40] = (int(bad[3]["spec"][40]) + 7) % 500 + 2
+    with pytest.raises(AssertionError):
+        trace_compare.compare(bad, run, run["cfg"].vocab_size, tol=0.02)

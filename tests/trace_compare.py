@@ -1,0 +1,103 @@
+"""Round-by-round comparison of a tree-decoding run with the reference's golden trace, "exact up to explained near-ties".
+
+The draft's beam candidates are ranked by sums of log-probabilities of fp16 (bf16) logits.  Two correct implementations
+whose GEMMs sum in different orders produce logits that differ by one unit in the last place now and then, so two candidates
+whose cumulative log-probs lie closer than that swap ranks -- and at the k-th place one enters the tree instead of the other
+(profiles/r5_long_runs_first_divergence.jsonl: margins of 1e-4 .. 1.4e-3 at the places where the HIP path and the reference's
+CPU run part).  Over ~100 rounds x 69 nodes this happens in some runs; it changes which speculation is verified (and thereby
+`count` / `num` by a few per cent), never the emitted tokens.  What this module accepts, and nothing else:
+  * a round whose tree (as a SET of root-to-node token paths) equals the reference's must give the same target predictions
+    and the same acceptance count;
+  * a round whose tree differs must differ, at the first level where it does, only by candidates that our own ranking places
+    within `tol` of its k-th candidate (the run is replayed asking the top-k operator for three candidates more than the
+    round uses);
+  * rounds are compared as long as the acceptance counts agree (after that the two runs are no longer aligned).
+"""
+import torch
+
+
+def level_bounds(tree_shape):
+    acc = [1]
+    for c in tree_shape:
+        acc.append(acc[-1] + c)
+    return acc
+
+
+def paths_of(spec, mask):
+    """spec [F] tokens, mask [F, F] 0/1 (row = ancestors incl. self and root): tuple of token paths, one per node."""
+    spec = spec.tolist()
+    out = []
+    for i in range(len(spec)):
+        anc = mask[i].nonzero().flatten().tolist()
+        out.append(tuple(spec[j] for j in anc))
+    return out
+
+
+class RoundSpy:
+    """Wraps an operator module: records per round the top-(k+3) candidate lists of every level and the inputs / result of
+    the tree collapse."""
+
+    def __init__(self, ops, extra=3):
+        self._ops, self._extra = ops, extra
+        self.rounds, self._cur = [], {"topk": []}
+
+    def __getattr__(self, n):
+        return getattr(self._ops, n)
+
+    def logprob_topk(self, logits, history, k):
+        v, i = self._ops.logprob_topk(logits, history, k + self._extra)
+        self._cur["topk"].append((v[0].cpu(), i[0].cpu(), k))
+        return v[:, :k].contiguous(), i[:, :k].contiguous()
+
+    def tree_collapse(self, all_spec, all_llm_pred, tree_mask, *a, **kw):
+        self._cur.update(spec=all_spec[0].cpu().clone(), pred=all_llm_pred[0].cpu().clone(), mask=tree_mask[0].cpu().clone())
+        r = self._ops.tree_collapse(all_spec, all_llm_pred, tree_mask, *a, **kw)
+        self._cur["acc"] = int(r[1][0])
+        self.rounds.append(self._cur)
+        self._cur = {"topk": []}
+        return r
+
+
+def compare(rounds, run, vocab, tol):
+    """Returns a dict of statistics; raises AssertionError on a difference that is not an explained near-tie."""
+    g_spec, g_mask, g_pred, g_acc = run["tr_all_spec"], run["tr_tree_mask"], run["tr_llm_pred"], run["tr_acc_num"]
+    acc = level_bounds(run["tree_shape"])
+    stats = {"rounds_compared": 0, "rounds_with_equal_trees": 0, "near_tie_rounds": 0, "worst_margin": 0.0, "aligned_until": None}
+    for r in range(min(len(rounds), g_spec.shape[0])):
+        rd = rounds[r]
+        ours, ref = paths_of(rd["spec"], rd["mask"]), paths_of(g_spec[r], g_mask[r].to(torch.int64))
+        stats["rounds_compared"] += 1
+        if set(ours) == set(ref):
+            stats["rounds_with_equal_trees"] += 1
+            pred_ours = {p: int(rd["pred"][i]) for i, p in enumerate(ours)}
+            pred_ref = {p: int(g_pred[r][i]) for i, p in enumerate(ref)}
+            assert pred_ours == pred_ref, f"round {r}: same draft tree, different target predictions"
+            assert rd["acc"] == int(g_acc[r]), f"round {r}: same draft tree, acceptance {rd['acc']} vs the reference's {int(g_acc[r])}"
+            continue
+        # first level whose path sets differ
+        for lvl in range(len(acc) - 1):
+            lo, hi = acc[lvl], acc[lvl + 1]
+            so, sr = set(ours[lo:hi]), set(ref[lo:hi])
+            if so != sr:
+                break
+        vals, idx, k = rd["topk"][lvl]
+        plo = 0 if lvl == 0 else acc[lvl - 1]
+        cand = {}
+        for v, i in zip(vals.tolist(), idx.tolist()):
+            parent = ours[plo + i // vocab]
+            cand[parent + (i % vocab,)] = v
+        kth = vals[k - 1].item()
+        for p in (sr - so):
+            assert p in cand, f"round {r} level {lvl}: the reference's candidate {p[-1]} is not among our top {k + 3}"
+            m = abs(cand[p] - kth)
+            assert m <= tol, f"round {r} level {lvl}: the reference's candidate {p[-1]} lies {m:.4f} from our k-th (tol {tol})"
+            stats["worst_margin"] = max(stats["worst_margin"], m)
+        for p in (so - sr):
+            m = abs(cand[p] - kth)
+            assert m <= tol, f"round {r} level {lvl}: our candidate {p[-1]} lies {m:.4f} above our k-th, yet the reference did not pick it"
+            stats["worst_margin"] = max(stats["worst_margin"], m)
+        stats["near_tie_rounds"] += 1
+        if rd["acc"] != int(g_acc[r]):
+            stats["aligned_until"] = r
+            break
+    return stats
