@@ -857,7 +857,7 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
 #define LS_WS_ABLATE 0
 #endif
 #ifndef LS_PART_WT
-#define LS_PART_WT 0
+#define LS_PART_WT 1
 #endif
 constexpr int WS_HEADROOM = LS_WS_HEADROOM;     // octaves between the first-64-keys maximum and the fixed soft-max reference
 constexpr int WS_QT = 5;                         // row tiles per pair
@@ -1466,8 +1466,10 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) {
 #if LS_PART_WT
-                    // diagnostic (-DLS_PART_WT=1, profiles/r5_part_wt.json): the partials leave the L2 as they are written
-                    // (agent-scope write-through) instead of in one write-back burst at the end of the kernel
+                    // the partials leave the L2 as they are written (agent-scope write-through, `sc1`) instead of in one
+                    // write-back burst at the end of the kernel: 37.6 MB of dirty lines cost the launch ~2 us at its end
+                    // (round 5 A/B inside the round, profiles/r5_part_wt.json: stage 1 at 16k 39.6 -> 37.4 us, round -0.04 ms;
+                    // 128k within noise; -DLS_PART_WT=0 rebuilds the plain-store variant.  `nt` stores were slower, round 4)
                     const f32x4 v_ = acc[dt][qt] * inv;
                     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(op + dt * 16), "v"(v_) : "memory");
 #else

@@ -17,7 +17,10 @@ for _ in range(3):
     ops.kvcache_attention(q, kc, vc, cache_seqlens=cl, kv_len_hint=L)
 torch.cuda.synchronize()
 ws = max(ops.workspace_tensors(), key=lambda t: t.numel())
-n_parts = 32
+from longspec_amd import _C
+import ctypes
+_d = ops._desc(q, kc, vc, cl, L)
+n_parts = _C.load().ls_attn_num_parts(ctypes.byref(_d))       # (31 since round 3: an odd split stride for calls without a new-key block)
 rows = 74 * H
 off = ((n_parts * rows * 128 * 4 + 255) // 256 * 256) + ((n_parts * rows * 4 + 255) // 256 * 256)
 raw = ws.view(torch.uint8)[off:off + 32 * 8].cpu().view(torch.int64).tolist()
