@@ -740,6 +740,34 @@ def test_saturating_keys_are_corrected_in_the_launch(ops, L, nats, nhot):
     assert us_hot <= 1.3 * us_plain, f"{us_hot:.1f} us with saturating keys vs {us_plain:.1f} us without"
 
 
+@pytest.mark.parametrize("sink_nats,L", [(8.0, 4096 + 64), (10.0, 4096 + 64), (10.0, 16384)])
+def test_attention_sink_with_a_diffuse_tail(ops, sink_nats, L):
+    """the warp-specialised kernel's reference sits WS_HEADROOM = 4 octaves above the maximum of a split's first
+    64 keys, so with an attention sink at key 0 (+8..10 nats on every query) the diffuse keys of split 0 lie 15-19 octaves below
+    the reference: their fp16 numerators are subnormal (below 2^-14) or flush to zero (below 2^-24).  What that costs: the
+    sink split's weights on its diffuse keys are rounded to a few bits -- against the oracle (fp32 soft-max, the reference's
+    flash-style rounding of P relative to the row maximum) the full call must stay inside the usual full-size bound; the
+    observed margin is recorded."""
+    from oracle import c_port
+    H, Hkv = 32, 8
+    q, k, v, _, _, tm = toy.verify_inputs(H, Hkv, 1, 5100 + int(sink_nats), a=4)
+    gen = torch.Generator(device="cpu").manual_seed(L + int(sink_nats))
+    kc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    vc = torch.zeros(1, L + 128, Hkv, 128, dtype=torch.float16)
+    kc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).half()
+    vc[:, :L] = torch.randn(1, L, Hkv, 128, generator=gen).half()
+    u = torch.zeros(128)
+    u[:16] = 1.0
+    a = 2.0
+    q = (q.float() + a * u).half()                                   # a direction all queries share
+    kc[0, 0] = (kc[0, 0].float() + sink_nats / (a * 16.0 / 128 ** 0.5) * u).half()       # the sink: key 0 of every kv head
+    cl = torch.tensor([L], dtype=torch.int32)
+    out = ops.verify_attention(g(q), g(k), g(v), g(kc), g(vc), g(cl), ops.pack_tree_mask(g(tm)), False, kv_len_hint=L)
+    ref = c_port.verify_attention(q, k, v, kc.clone(), vc.clone(), L, tm, False)
+    worst, mean = assert_close_rel(out, ref, ulps=2.0, what=f"sink +{sink_nats} nats at key 0, L={L}")
+    print(f"sink +{sink_nats} nats, L={L}: worst |diff| / bound {worst:.2f}, mean |diff| {mean:.2f} ulp(rms)")
+
+
 @pytest.mark.parametrize("late", [True, False])
 def test_saturating_key_behind_the_noted_blocks(ops, late):
     """the bitmap of blocks to correct covers 2048 blocks = 65536 keys of ONE split.  With a forced single
