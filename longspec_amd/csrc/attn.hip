@@ -1452,6 +1452,11 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         }
         __syncthreads();                           // the pair's m*scale is in LDS
         WS_MARK(5);                                // ready to write the partial
+#if LS_PART_WT
+        // this (split, batch element)'s slab of the partials as a buffer resource: [sq][H][D] fp32, < 4 GB by construction
+        const __amdgpu_buffer_rsrc_t part_rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.parts_o + ((long)split * p.b + bi) * p.sq * p.H * D, 0, p.sq * p.H * D * 4, 0x00020000);
+#endif
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const float lt = __shfl(lacc[qt][0], l15);       // (lanes g4 == 0 hold it)
@@ -1466,12 +1471,17 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) {
 #if LS_PART_WT
-                    // the partials leave the L2 as they are written (agent-scope write-through, `sc1`) instead of in one
+                    // the partials leave the L2 as they are written (agent-scope write-through, `sc1` = aux 16) instead of in one
                     // write-back burst at the end of the kernel: 37.6 MB of dirty lines cost the launch ~2 us at its end
-                    // (round 5 A/B inside the round, profiles/r5_part_wt.json: stage 1 at 16k 39.6 -> 37.4 us, round -0.04 ms;
-                    // 128k within noise; -DLS_PART_WT=0 rebuilds the plain-store variant.  `nt` stores were slower, round 4)
+                    // (round 5 A/B inside the round, profiles/r5_part_wt.json; -DLS_PART_WT=0 rebuilds the plain-store variant;
+                    // `nt` stores were slower, round 4).  Through the compiler's buffer-store builtin, NOT inline asm: a VALU
+                    // write of a > 64-bit store's data registers needs two wait states behind the store, which the compiler only
+                    // inserts for stores it knows -- the asm form of this line gave wrong partials in one build and right ones
+                    // in another.
+                    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
                     const f32x4 v_ = acc[dt][qt] * inv;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(op + dt * 16), "v"(v_) : "memory");
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v_), part_rs,
+                                                           (unsigned)((((long)rrow[qt] * p.H + head) * D + g4 * 4 + dt * 16) * 4), 0, 16);
 #else
                     *reinterpret_cast<f32x4*>(op + dt * 16) = acc[dt][qt] * inv;
 #endif

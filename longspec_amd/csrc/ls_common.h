@@ -182,7 +182,9 @@ struct ls_xchg {
 // acknowledged" is s_waitcnt vmcnt(0) and not a release fence -- a system-scope release writes the whole L2 back
 // (the split partials of the attention call are still dirty in it: measured +35 us per call with fences).
 __device__ __forceinline__ void xchg_store16(void* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    // (s_nop 1: a VALU write of a > 64-bit store's data registers needs two wait states behind the store -- the compiler
+    // inserts them for its own stores only, and is free to reuse `v`'s registers right behind this statement)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void xchg_store4(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
