@@ -713,14 +713,19 @@ def main():
             out_v[:, 0] = first
             vs = m.begin_vanilla_decode(out_v, lens.clone(), lens.clone(), L_total)
             vs.use_graphs = vs.use_graphs and not args.no_graphs          # same treatment as the tree rounds
-            vs.step = m.GRAPH_AFTER - 2                                   # capture now, not after GRAPH_AFTER tokens
-            for i in range(args.vanilla_steps + 4):                       # steps 1-2 eager, 3 captures, the rest replay
-                if i == 4:
-                    torch.cuda.synchronize()
-                    tv = time.time()
-                m.vanilla_step(vs)
-            torch.cuda.synchronize()
-            vanilla_tps = args.vanilla_steps / (time.time() - tv)
+            graph_after, m.GRAPH_AFTER = m.GRAPH_AFTER, 2                 # capture now, not after GRAPH_AFTER tokens
+            try:
+                for i in range(args.vanilla_steps + 4):                   # steps 1-2 eager, 3 captures, the rest replay
+                    if i == 4:
+                        torch.cuda.synchronize()
+                        tv = time.time()
+                    m.vanilla_step(vs)
+                torch.cuda.synchronize()
+                vanilla_tps = args.vanilla_steps / (time.time() - tv)
+            finally:
+                m.GRAPH_AFTER = graph_after
+            if vs.use_graphs and vs.graph_captures != 1:                  # the timed steps must be replays of ONE capture
+                raise RuntimeError(f"vanilla denominator: {vs.graph_captures} graph captures inside the timed steps")
         out["vanilla_tokens_per_s"] = round(vanilla_tps, 3)
         out["speedup_vs_vanilla"] = round(value / vanilla_tps, 3)
         if not args.no_cpu_baseline:

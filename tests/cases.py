@@ -152,6 +152,9 @@ def generate_runs(family="llama"):
             d[k] = _t(g[f"{name}_{k}"])
         for k in ("vanilla_num", "tree_count", "tree_num", "chain_count", "chain_num"):
             d[k] = int(g[f"{name}_{k}"])
+        for k in ("vanilla_top2_ids", "vanilla_top2_logits"):         # long runs: the reference's own decision margins
+            if f"{name}_{k}" in g:
+                d[k] = _t(g[f"{name}_{k}"])
         yield d
 
 

