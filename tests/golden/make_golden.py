@@ -212,7 +212,9 @@ def gen_dense_twin(llama, train_llama):
     attention outputs are captured at the o_proj seam (o_proj = identity)."""
     arrays = {}
     idx = 0
-    for (H, Hkv, L) in ((4, 1, 300), (2, 2, 1024), (4, 1, 37)):
+    # (5, 1, ...): QwQ's GQA-5 -- 370 verification rows: the general kernel below 4096 keys, two 12-tile row chunks on the
+    # warp-specialised kernel from 4096 on (round 5: the layout every configs[4] call runs in had no golden of its own)
+    for (H, Hkv, L) in ((4, 1, 300), (2, 2, 1024), (4, 1, 37), (5, 1, 500), (5, 1, 4200)):
         seed = 6000 + idx
         q, k, v, kc, vc, tm = _verify_inputs(H, Hkv, L, seed)
         R = q.shape[1]
@@ -848,7 +850,7 @@ def gen_draft_attention(llama_glide):
     GlideAttention.decoding / .tree_decoding (real Triton kernel, interpreter)."""
     arrays = {}
     idx = 0
-    for (H, Hkv, p) in ((4, 1, 700), (2, 2, 100), (4, 1, 520)):
+    for (H, Hkv, p) in ((4, 1, 700), (2, 2, 100), (4, 1, 520), (5, 1, 700), (7, 1, 530)):      # (+ GQA 5 / 7: the Qwen2 layouts)
         seed = 8000 + idx
         Lalloc = p + 200
         kc0 = torch.zeros(1, Lalloc, Hkv, 128, dtype=torch.float16)
@@ -910,6 +912,11 @@ def main():
         return
     if "--only-chain-stochastic" in sys.argv:
         gen_chain_stochastic(llama, llama_glide)
+        return
+    if "--only-attention" in sys.argv:        # the two attention fixtures that gained cases in round 5
+        gen_dense_twin(llama, train_llama)
+        install_triton_stubs()
+        gen_draft_attention(llama_glide)
         return
     if "--only-decoding-torch" in sys.argv:
         gen_decoding_torch(llama)
