@@ -269,6 +269,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_chunk_kernel(const typename E
 
 // mode 0: joint top-k over all rows of log_softmax(row) + history[row]; out_idx = row * V + column (sorted)
 // mode 1: per-row argmax of the logits; out_idx[row] = column
+// MAXOWN = candidates a thread holds in registers: ceil(R * nchunks * k / 256) rounded up to 4, 8, 16 or 20.  Every extraction round
+// scans all MAXOWN slots of every thread, empty or not -- a 4-row level (1024 candidates) took as long as a 16-row one (round 5:
+// the draft passes' merge 21 us for both; profiles/r5_round_timeline_128k.json).
+template <int MAXOWN>
 __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __restrict__ ws, int R, int V, int k, int nchunks,
                                                                 const float* __restrict__ history, int mode,
                                                                 float* __restrict__ out_vals, int64_t* __restrict__ out_idx) {
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const float* __r
     // reductions (no barrier), wave 0 then merges the 4 sorted lists: the output is sorted descending, ties to
     // the smaller flat index.
     const int ncand = R * nchunks * k;
-    constexpr int MAXOWN = 20;          // ncand <= 256 * 20 (checked on the host)
+    // ncand <= 256 * MAXOWN (the host picks the instantiation)
     unsigned long long pk[MAXOWN];      // (ordered key of the value) << 32 | ~flat index; 0 = empty
     float2 ld[MAXOWN];
     int crow[MAXOWN];
@@ -410,8 +414,19 @@ static int stage2(const float* records, int rows, int vocab, int k, int nslots, 
         if (!out_vals) LS_FAIL(LS_ERR_INVALID_ARG, "%s: null out_vals", what);
     }
     const int grid2 = mode == 1 ? (rows + TK_THREADS - 1) / TK_THREADS : 1;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode, out_vals,
-                       out_idx);
+    const long ncand = mode == 1 ? 0 : (long)rows * nslots * k;
+    if (ncand <= 256L * 4)
+        hipLaunchKernelGGL(topk_merge_kernel<4>, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode,
+                           out_vals, out_idx);
+    else if (ncand <= 256L * 8)
+        hipLaunchKernelGGL(topk_merge_kernel<8>, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode,
+                           out_vals, out_idx);
+    else if (ncand <= 256L * 16)
+        hipLaunchKernelGGL(topk_merge_kernel<16>, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode,
+                           out_vals, out_idx);
+    else
+        hipLaunchKernelGGL(topk_merge_kernel<20>, dim3(grid2), dim3(TK_THREADS), 0, s, records, rows, vocab, k, nslots, history, mode,
+                           out_vals, out_idx);
     LS_CHECK_LAUNCH("topk_merge_kernel");
     return LS_OK;
 }
