@@ -58,11 +58,16 @@ def _snapshot_complete(path: str) -> bool:
     return all(len(have) == total for total, have in shards.items())
 
 
-def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
+def resolve_path(path_or_id: str, need_tensors: bool = True, revision: Optional[str] = None) -> str:
     """A local checkpoint directory / file as is; anything else is taken as a Hugging Face hub id
     (``lmsys/vicuna-7b-v1.5-16k``, ``sail/longspec-vicuna-7b-v1.5-16k`` ... -- what
     ``inference_long-bench.py:41-62`` passes to ``from_pretrained``) and resolved through the local HF cache first,
-    then -- if the machine has network access -- downloaded with ``snapshot_download``."""
+    then -- if the machine has network access -- downloaded with ``snapshot_download``.
+
+    The cache wins: a COMPLETE cached snapshot (or, for ``need_tensors=False``, a cached ``config.json``) is returned without
+    asking the hub, so a repository updated since is not refreshed.  To force a refresh pass ``revision`` (a commit
+    hash / tag / branch: the cache is keyed by it) or clear the cache entry; ``HF_HUB_OFFLINE=1`` keeps the second, networked
+    pass from being tried at all."""
     if os.path.exists(path_or_id):
         return path_or_id
     try:
@@ -72,7 +77,7 @@ def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
     patterns = ["*.json", "*.safetensors", "*.bin", "*.pth", "*.pt", "*.model"]
     cached = None
     try:
-        cached = snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns)
+        cached = snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns, revision=revision)
         # A snapshot can be PARTIAL: `AutoConfig.from_pretrained(hub_id)` (inference_long-bench.py:104) caches config.json alone,
         # and the local-only pass cannot tell (no tree listing is cached).  Only a snapshot that holds its tensors -- every shard
         # its index names -- is complete; anything else goes on to the networked pass, which fetches what is missing.
@@ -83,7 +88,9 @@ def resolve_path(path_or_id: str, need_tensors: bool = True) -> str:
     except Exception:
         pass
     try:
-        return snapshot_download(path_or_id, allow_patterns=patterns)
+        if os.environ.get("HF_HUB_OFFLINE", "") not in ("", "0"):
+            raise ConnectionError("HF_HUB_OFFLINE is set")
+        return snapshot_download(path_or_id, allow_patterns=patterns, revision=revision)
     except Exception as e:
         if cached is not None and os.path.exists(os.path.join(cached, "config.json")) and not need_tensors:
             return cached                        # config-only consumers (load_config) can live with the partial snapshot

@@ -200,9 +200,11 @@ __device__ __forceinline__ void xchg_wait_flag(const char* box, XCtl* ctl, int p
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(box) + parity * XCHG_MAX_WORLD + src;
     unsigned spins = 0;
     if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // latched: never wait twice
-    // RELAXED polls and no acquire behind them: the mailbox is UNCACHED device memory (ls_xchg_create), so the record is read
-    // from HBM whatever the caches hold, the reads are issued behind this loop (and behind the caller's barrier), and everything
-    // else the merge reads was written by earlier kernels of this stream.  An acquiring poll is `buffer_inv sc0 sc1` per poll in
+    // RELAXED polls and no acquire behind them: the mailbox is UNCACHED device memory (ls_xchg_create) and the merge reads the
+    // records with `nt` loads, which bypass this CU's L1 (attn_finish_kernel<XM = 2>, round 5: nothing in the memory model kept
+    // a stale L1 line of the same parity slot out of a plain load), the reads are issued behind this loop (and behind the
+    // caller's barrier), and everything else the merge reads was written by earlier kernels of this stream.  Validated on gfx950
+    // (MI355X) with two ranks on ONE GPU only -- no multi-GPU node was available in rounds 1-5.  An acquiring poll is `buffer_inv sc0 sc1` per poll in
     // every workgroup -- it throws the tree part, written by the launch in front, out of the L2 (round 4: 23.7 -> 22.0 us per
     // exchange at 16k rows per rank, profiles/r4_xchg_arrive_relaxed.json).
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
