@@ -15,7 +15,7 @@ import glob
 import json
 import os
 from types import SimpleNamespace
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -66,8 +66,8 @@ def resolve_path(path_or_id: str, need_tensors: bool = True, revision: Optional[
 
     The cache wins: a COMPLETE cached snapshot (or, for ``need_tensors=False``, a cached ``config.json``) is returned without
     asking the hub, so a repository updated since is not refreshed.  To force a refresh pass ``revision`` (a commit
-    hash / tag / branch: the cache is keyed by it) or clear the cache entry; ``HF_HUB_OFFLINE=1`` keeps the second, networked
-    pass from being tried at all."""
+    hash / tag / branch: the cache is keyed by it) or clear the cache entry; with ``HF_HUB_OFFLINE=1`` huggingface_hub itself
+    refuses the second, networked pass."""
     if os.path.exists(path_or_id):
         return path_or_id
     try:
@@ -75,9 +75,10 @@ def resolve_path(path_or_id: str, need_tensors: bool = True, revision: Optional[
     except ImportError as e:                     # pragma: no cover
         raise FileNotFoundError(f"{path_or_id!r} is not a local path and huggingface_hub is not installed") from e
     patterns = ["*.json", "*.safetensors", "*.bin", "*.pth", "*.pt", "*.model"]
+    rev = {"revision": revision} if revision is not None else {}
     cached = None
     try:
-        cached = snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns, revision=revision)
+        cached = snapshot_download(path_or_id, local_files_only=True, allow_patterns=patterns, **rev)
         # A snapshot can be PARTIAL: `AutoConfig.from_pretrained(hub_id)` (inference_long-bench.py:104) caches config.json alone,
         # and the local-only pass cannot tell (no tree listing is cached).  Only a snapshot that holds its tensors -- every shard
         # its index names -- is complete; anything else goes on to the networked pass, which fetches what is missing.
@@ -88,9 +89,7 @@ def resolve_path(path_or_id: str, need_tensors: bool = True, revision: Optional[
     except Exception:
         pass
     try:
-        if os.environ.get("HF_HUB_OFFLINE", "") not in ("", "0"):
-            raise ConnectionError("HF_HUB_OFFLINE is set")
-        return snapshot_download(path_or_id, allow_patterns=patterns, revision=revision)
+        return snapshot_download(path_or_id, allow_patterns=patterns, **rev)
     except Exception as e:
         if cached is not None and os.path.exists(os.path.join(cached, "config.json")) and not need_tensors:
             return cached                        # config-only consumers (load_config) can live with the partial snapshot
