@@ -859,11 +859,25 @@ __device__ __forceinline__ void partial_entry(const AttnK& p, char* smem) {
 #ifndef LS_PART_WT
 #define LS_PART_WT 1
 #endif
+// LS_WS_PF = 1 (round 5): the operand fragments of the NEXT step are requested from the LDS in FRONT of the step's barrier and
+// are NOT waited for there (lgkmcnt counts in order: the P stores in front of them are) -- the S wave's 8 K fragments of block
+// j+2, the O wave's 16 V^T fragment halves of block j -- so that their latency runs under the barrier and both waves have matrix
+// work the moment it releases them.  The in-round ablations (profiles/r5_ws_ablations_inround.log) price the exposed fragment
+// reads at 34 us of a 165 us call at 128k, as much as either half of the MFMAs.  Costs one block of DMA look-ahead: a block
+// must be complete one barrier earlier.  (Round 4's LS_WS_PIPE2 also moved the reads in front of the barrier, but waited for them
+// there and moved the DMA issue with them: slower.)
+#ifndef LS_WS_PF
+#define LS_WS_PF 0
+#endif
 constexpr int WS_HEADROOM = LS_WS_HEADROOM;     // octaves between the first-64-keys maximum and the fixed soft-max reference
 constexpr int WS_QT = 5;                         // row tiles per pair
-constexpr int WS_LA = 5;                         // blocks of DMA look-ahead (80 KB of K+V in flight per CU)
-constexpr int WS_NK = WS_LA + 1;                 // K ring stages: block b lives from step b-1-LA to step b-1
-constexpr int WS_NV = WS_LA + 3;                 // V ring stages: ... to step b+1
+constexpr int WS_PF = LS_WS_PF;                  // 1: fragments of the next step are fetched in front of the barrier (see LS_WS_PF)
+constexpr int WS_LA = 5 + WS_PF;                 // blocks of DMA look-ahead (80 KB of K+V in flight per CU)
+// Ring stages.  K: block b lives from step b-1-LA to step b-1;  V: ... to step b+1.  WS_PF reads a block's fragments one barrier
+// earlier, so both rings recycle a slot one step earlier and the SAME 14 slots carry one more block of look-ahead (the reads in
+// front of a barrier may still be in flight when the first DMA piece behind it is issued: that piece lands >= 1 us later).
+constexpr int WS_NK = WS_LA + 1 - WS_PF;
+constexpr int WS_NV = WS_LA + 3 - WS_PF;
 constexpr int WS_BLK_B = 32 * ROWB;              // 8 KB: 32 keys of K (or V)
 constexpr int WS_PBUF_B = 4 * WS_QT * 1024;      // one P buffer: 4 pairs x 5 row tiles x (64 lanes x 16 B)
 constexpr int WS_RING_B = (WS_NK + WS_NV) * WS_BLK_B;
@@ -1003,9 +1017,9 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
         wait_vmcnt(need < nblocks ? 2 * younger : 0);
     };
     auto pass_head = [&]() {
-        const int n0 = min(nblocks, WS_LA + 1);
+        const int n0 = min(nblocks, WS_NK);        // (WS_PF: block LA follows behind the look's barrier, `look_done`)
         for (int b = 0; b < n0; ++b) dma(b);
-        wait_block(1, n0);                         // blocks 0 and 1 (reference look, first QK)
+        wait_block(1 + WS_PF, n0);                 // blocks 0 and 1 (reference look, first QK) [+ block 2: read in front of barrier 0]
         __builtin_amdgcn_s_barrier();
     };
     auto step_head = [&](int j) {
@@ -1014,7 +1028,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
 #endif
     };
     auto step_tail = [&](int j) {
-        wait_block(j + 2, min(nblocks, j + 2 + WS_LA));                 // K(j+2) is multiplied at step j+1
+        wait_block(j + 2 + WS_PF, min(nblocks, j + 2 + WS_LA));         // K(j+2) is multiplied at step j+1 (WS_PF: K(j+3) is read in front of barrier j+1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // P writes / reads of this step are done
         __builtin_amdgcn_s_barrier();
     };
@@ -1098,7 +1112,31 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                 for (int qt = 0; qt < QT; ++qt)
                     if (row0 + qt * 16 + l15 >= p.M) mref[qt] = INFINITY;      // padding rows: p = 2^(0 - inf) = 0
             }
+            typename E::V8 kfr[4][2];              // WS_PF: the K fragments of the block whose scores the next step forms
+            auto load_kf = [&](unsigned kbase) {
+                int kx = tb.kx;
+                asm volatile("" : "+v"(kx));       // see qk_block
+                const unsigned kb = kbase + tb.kb;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) kfr[k4][kt] = lds_read16<typename E::V8>(kb + ((k4 ^ kx) << 6) + kt * 16 * ROWB);
+            };
+            auto qk_from_kfr = [&](f32x4 (&sx)[2][QT]) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) sx[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) sx[kt][qt] = E::mfma(kfr[k4][kt], qf[qt][k4], sx[kt][qt]);
+            };
+            if (WS_PF && nblocks > 1) load_kf(k_addr(1));                     // (block 1 is complete since pass_head's barrier)
             __builtin_amdgcn_s_barrier();          // K(0) is consumed: step 0 may overwrite its slot
+            if (WS_PF && WS_LA < nblocks) dma(WS_LA);      // (the ring's last look-ahead block takes K(0)'s slot)
             WS_MARK(2);                            // reference look done
             typedef __attribute__((address_space(3))) typename E::V8 lds_v8;
             // soft-max numerators of block j (reference mref, fixed) -> P(j) in LDS.  The row sums are NOT formed here: the
@@ -1138,7 +1176,12 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     if (j < nblocks) {
                         row_max(s_cur, mref);
                         if (j + 1 < nblocks) {
-                            qk_block_pf<E, QT>(s_cur, qf, tb, k_addr(j + 1));
+                            if constexpr (WS_PF) {         // (the rings recycle K(j+1)'s slot at this step's head: fragments in registers)
+                                qk_from_kfr(s_cur);
+                                if (j + 2 < nblocks) load_kf(k_addr(j + 2));
+                            } else {
+                                qk_block_pf<E, QT>(s_cur, qf, tb, k_addr(j + 1));
+                            }
                             mask_tail(s_cur, j + 1);
                         }
                     }
@@ -1151,24 +1194,40 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                     WS_T0();
                     step_head(j);
                     WS_TS(0);
-                    qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
-                    softmax_store(j, s_in);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // all 8 K-fragment LDS reads first,
-                    __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);            // VALU work while they are in flight
+                    if constexpr (WS_PF) {
+                        // S^T of block j+1 from the fragments fetched in front of the last barrier, under the exponentials of block j
+                        qk_from_kfr(s_next);
+                        softmax_store(j, s_in);
 #pragma unroll
-                    for (int i = 0; i < 8 * QT; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);         // 6 VALU
+                        for (int i = 0; i < 8 * QT; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // 6 VALU
+                        }
+                        if constexpr (decltype(masked)::value) mask_tail(s_next, j + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j + 2 < nblocks) load_kf(k_addr(j + 2));               // complete since barrier j-1; waited for by its first MFMA
+                    } else {
+                        qk_block_pf<E, QT>(s_next, qf, tb, k_addr(j + 1));
+                        softmax_store(j, s_in);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);         // all 8 K-fragment LDS reads first,
+                        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);        // VALU work while they are in flight
+#pragma unroll
+                        for (int i = 0; i < 8 * QT; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // 6 VALU
+                        }
+                        if constexpr (decltype(masked)::value) mask_tail(s_next, j + 1);
                     }
-                    if constexpr (decltype(masked)::value) mask_tail(s_next, j + 1);
                     WS_TS(1);
                     // K(j+2) is multiplied at step j+1.  In the steady state exactly LA-1 younger blocks (2 pieces each) are in
                     // flight: one immediate wait instead of the compare / branch ladder of wait_block (measured: 155-170 ns of
                     // a 1.4 us step went into that ladder)
-                    if constexpr (decltype(fixed_wait)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1)) : "memory");
-                    else wait_block(j + 2, min(nblocks, j + 2 + WS_LA));
+                    if constexpr (decltype(fixed_wait)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1 - WS_PF)) : "memory");
+                    else wait_block(j + 2 + WS_PF, min(nblocks, j + 2 + WS_LA));
                     WS_TS(2);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // the P stores are done (LDS operations of a wave complete in order: the 8 fragment reads behind them may still fly)
+                    if (WS_PF && j + 2 < nblocks) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     WS_TS(3);
                     __builtin_amdgcn_s_barrier();
                     WS_TS(4);
@@ -1311,6 +1370,28 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
             }
             pass_head();
             __builtin_amdgcn_s_barrier();          // the S waves' look at blocks 0 and 1 is over
+            if (WS_PF && WS_LA < nblocks) dma(WS_LA);
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            union VF {
+                struct { s16x4 a, b; } s;
+                typename E::V8 v;
+            } vf[8];                               // all 8 V^T fragments before the first MFMA (WS_PF: fetched in front of the last barrier)
+            auto load_vf = [&](int blk) {
+                int vx = tb.vx;
+                asm volatile("" : "+v"(vx));       // see qk_block
+                const unsigned vb = v_addr(blk) + tb.vb;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const unsigned va = vb + ((dt ^ vx) << 5);
+#if LS_WS_ABLATE & 16
+                    vf[dt].v = ones;
+                    asm volatile("" ::"v"(va));
+#else
+                    vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
+                    vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
+#endif
+                }
+            };
 #pragma unroll 1
             for (int j = 0; j <= nblocks; ++j) {
                 WS_T0();
@@ -1327,25 +1408,7 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         pf[qt] = lds_read16<typename E::V8>(p_base + (jj & 1) * WS_PBUF_B + qt * 1024);
 #endif
                     }
-                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                    int vx = tb.vx;
-                    asm volatile("" : "+v"(vx));           // see qk_block
-                    const unsigned vb = v_addr(jj) + tb.vb;
-                    union VF {
-                        struct { s16x4 a, b; } s;
-                        typename E::V8 v;
-                    } vf[8];                               // all 8 V^T fragments before the first MFMA
-#pragma unroll
-                    for (int dt = 0; dt < 8; ++dt) {
-                        const unsigned va = vb + ((dt ^ vx) << 5);
-#if LS_WS_ABLATE & 16
-                        vf[dt].v = ones;
-                        asm volatile("" ::"v"(va));
-#else
-                        vf[dt].s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)va);
-                        vf[dt].s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 16 * ROWB));
-#endif
-                    }
+                    if constexpr (!WS_PF) load_vf(jj);
 #if LS_WS_ABLATE & 4
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt) asm volatile("" ::"v"(vf[dt].v));
@@ -1375,12 +1438,19 @@ __device__ __forceinline__ void prefix_path_ws(const AttnK& p, char* smem, int s
                         sat_prev = tot;
                     }
                 }
+                if constexpr (WS_PF) {
+                    // V^T of block j, multiplied at step j+1 (the block is complete since barrier j-2): requested here, behind
+                    // this step's MFMAs, and not waited for in front of the barrier
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (mode != 1 && j < nblocks) load_vf(j);
+                }
                 WS_TS(1);
                 // steady state: exactly LA-1 younger blocks (2 pieces each) are in flight behind K(j+2) -- see the S role
-                if (j + 2 + WS_LA <= nblocks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1)) : "memory");
-                else wait_block(j + 2, min(nblocks, j + 2 + WS_LA));
+                if (j + 2 + WS_LA <= nblocks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WS_LA - 1 - WS_PF)) : "memory");
+                else wait_block(j + 2 + WS_PF, min(nblocks, j + 2 + WS_LA));
                 WS_TS(2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (WS_PF: the P fragments of this step were consumed by its MFMAs; only the fragment reads above are outstanding)
+                if constexpr (!WS_PF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 WS_TS(3);
                 __builtin_amdgcn_s_barrier();
                 WS_TS(4);
