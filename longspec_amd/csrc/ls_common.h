@@ -195,17 +195,32 @@ __device__ __forceinline__ void xchg_raise_flag(char* box, int parity, int rank,
     __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (ordered behind the data by the waits above)
 }
 
+// Loads of a record that a PEER stored into the local mailbox: SYSTEM scope (sc0 sc1 = aux 17 of the raw buffer load).  `nt` is
+// only a streaming hint on gfx94x / gfx950; what keeps a stale line of this CU's L1 (or a non-coherent L2 line) out of the
+// merge is the scope of the load.  Through the compiler's builtin, so that its s_waitcnt bookkeeping covers them.
+// `bytes` < 2 GB (a mailbox slot is a few MB).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xchg_record_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffull ? bytes : 0x7fffffffull), 0x00020000);
+}
+__device__ __forceinline__ f32x4 xchg_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 17));
+}
+__device__ __forceinline__ float xchg_load4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 17));
+}
+
 // poll flag[parity][src] of the local mailbox until rank `src` has delivered epoch `epoch` (one thread per source)
 __device__ __forceinline__ void xchg_wait_flag(const char* box, XCtl* ctl, int parity, int src, unsigned long long epoch) {
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(box) + parity * XCHG_MAX_WORLD + src;
     unsigned spins = 0;
     if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // latched: never wait twice
-    // RELAXED polls and no acquire behind them: the mailbox is UNCACHED device memory (ls_xchg_create) and the merge reads the
-    // records with `nt` loads, which bypass this CU's L1 (attn_finish_kernel<XM = 2>, round 5: nothing in the memory model kept
-    // a stale L1 line of the same parity slot out of a plain load), the reads are issued behind this loop (and behind the
-    // caller's barrier), and everything else the merge reads was written by earlier kernels of this stream.  Validated on gfx950
-    // (MI355X) with two ranks on ONE GPU only -- no multi-GPU node was available in rounds 1-5.  An acquiring poll is `buffer_inv sc0 sc1` per poll in
-    // every workgroup -- it throws the tree part, written by the launch in front, out of the L2 (round 4: 23.7 -> 22.0 us per
+    // RELAXED polls and no acquire behind them: the mailbox is UNCACHED device memory (ls_xchg_create), the merge reads the
+    // records with system-scope loads (xchg_load16 / xchg_load4: served beyond this CU's L1 whatever it holds -- `nt`, used in
+    // round 5, is only a cache-policy hint), those loads are issued behind this loop and behind the caller's barrier, and
+    // everything else the merge reads was written by earlier kernels of this stream.  Validated on gfx950 (MI355X) with two
+    // ranks on ONE GPU only -- no multi-GPU node was available in rounds 1-6.  An acquiring poll is `buffer_inv sc0 sc1` per poll
+    // in every workgroup -- it throws the tree part, written by the launch in front, out of the L2 (round 4: 23.7 -> 22.0 us per
     // exchange at 16k rows per rank, profiles/r4_xchg_arrive_relaxed.json).
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
         __builtin_amdgcn_s_sleep(32);

@@ -60,10 +60,12 @@ __global__ __launch_bounds__(XCHG_THREADS) void xchg_wait_kernel(const char* __r
     const f32x4* in = reinterpret_cast<const f32x4*>(box + XCHG_DATA_OFF + ((size_t)(parity * world + src) * cap_floats) * 4);
     f32x4* out = reinterpret_cast<f32x4*>(gathered + (size_t)src * stride_floats);
     const size_t base = (size_t)blockIdx.x * XCHG_CHUNK16;
+    // the record was written by a PEER: system-scope loads (sc0 sc1), see xchg_load16
+    const __amdgpu_buffer_rsrc_t rs = xchg_record_rsrc(in, n16 * 16);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const size_t i = base + u * XCHG_THREADS + threadIdx.x;
-        if (i < n16) out[i] = __builtin_nontemporal_load(in + i);
+        if (i < n16) out[i] = xchg_load16(rs, (unsigned)(i * 16));
     }
 }
 

@@ -326,6 +326,7 @@ class LlamaGlide(LlamaForCausalLM):
     def vanilla_step(self, vs):
         """Decode one token.  On a GPU the step is captured into a HIP graph after GRAPH_AFTER eager steps and replayed."""
         vs.step += 1
+        produced = False                                              # this call's token is already in output_ids (ADVICE r5)
         if vs.use_graphs:
             try:
                 if vs.graph is not None and vs.step + 1 > vs.graph_bound:     # (step s reads s rows beyond the prompt's)
@@ -339,6 +340,7 @@ class LlamaGlide(LlamaForCausalLM):
                     vs.graph_stream.wait_stream(cur)
                     with torch.cuda.stream(vs.graph_stream):          # warm the capture stream's workspaces
                         self._vanilla_device(vs)
+                    produced = True
                     cur.wait_stream(vs.graph_stream)
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph, stream=vs.graph_stream):
@@ -355,8 +357,13 @@ class LlamaGlide(LlamaForCausalLM):
                 import warnings
                 warnings.warn(f"HIP-graph capture of the vanilla step failed ({type(e).__name__}: {e}); running eagerly")
                 vs.use_graphs = False
-                if vs.graph_stream is not None:                       # the warm-up step already produced this token
+                vs.graph = None
+                if produced:                                          # the warm-up step already produced this call's token
+                    if vs.graph_stream is not None:
+                        torch.cuda.current_stream().wait_stream(vs.graph_stream)
                     return
+                # anything else (a failure in front of the warm-up step -- _set_hints, wait_stream -- or in a later
+                # replay()) has not decoded this call's token: fall through to the eager step
         self._set_hints(vs.P + vs.step, vs.P + vs.step)
         self._vanilla_device(vs)
 
@@ -876,7 +883,12 @@ class LlamaGlide(LlamaForCausalLM):
             # the reference fails here too: gamma + 2 accepted tokens do not fit its veri_spec buffer (:1081)
             raise RuntimeError(f"stochastic round: {a} accepted tokens + {st.Fn - 1} tree nodes exceed the {st.R}-row "
                                f"verification batch (the reference raises at llama_glide.py:1081 in the same state)")
-        self._set_hints(st.P + st.output_ids.size(1) + st.R, st.P + st.output_ids.size(1) + st.Fn)
+        # host bound of the valid rows, per round as in the eager T = 0 path: every round reads acc_num on the host anyway, and
+        # the lengths (cache_lens advances by a - 1 per round, the draft's by acc_num) never exceed P + the sum of the accepted
+        # counts -- NOT the whole token budget, which sized a 1k-prompt / 20k-budget run for 21k-row launches from round 1
+        # 
+        bound = min(st.emitted, st.output_ids.size(1))
+        self._set_hints(st.P + bound + st.R, st.P + bound + st.Fn)
         llm_logits = self._round_device(st, a)                               # [bsz, Fn, V]
         st.cache_lens += a - 1                                               # :1094
         acc_ids, acc_num = self.verify_stochastic(st.all_spec, st.tree_mask, llm_logits, st.spec_logits, st.temperature)
@@ -885,6 +897,7 @@ class LlamaGlide(LlamaForCausalLM):
         st.output_ids[torch.arange(st.bsz, device=acc_ids.device)[:, None], cols] = acc_ids          # :1102
         st.target_cache_lens_for_draft += acc_num.to(torch.int32)            # :1110
         n = int(acc_num[0])
+        st.emitted += int(acc_num.max()) if st.bsz > 1 else n                # host mirror: an upper bound of every length's growth
         st.count += n - 1
         st.num += st.bsz
         st.tree_mask.fill_(0)
