@@ -348,6 +348,19 @@ int ls_chain_commit(int64_t* llm_verify_output, int64_t* spec_buffer, int b, int
 int ls_embed_rows(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int n,
                   void* out, void* stream);
 
+/* Head of a decode pass in one launch: `embed_tokens(ids)` (llama.py:579, llama_glide.py:1003,1030) + the pass's RoPE table
+ * (LlamaRotaryEmbedding.forward, llama.py:580 / llama_glide.py:1005-1006,1032-1033) + the first decoder layer's
+ * `input_layernorm` (llama.py:487 via LlamaDecoderLayer.forward, llama_glide.py:437).  Bit-identical to
+ * ls_embed_rows + ls_rope_cos_sin + ls_rmsnorm_fwd (the same device code); rows <= 128.
+ *   ids [rows] int64; position of row i = positions[i] (int64) if given, else pos_base[i / q_len] + i % q_len + pos_add
+ *   (int32 lengths on the device: `arange(q_len) + cache_lens[:, None]`);
+ *   embeds [rows,hidden] = table[ids] (the residual stream), normed [rows,hidden] = RMSNorm(embeds) * norm_weight,
+ *   cosv / sinv [rows,128]. */
+int ls_pass_head(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int rows,
+                 const int64_t* positions, const int32_t* pos_base, int q_len, int pos_add, const float* inv_freq,
+                 float attention_scaling, const void* norm_weight, float eps, void* embeds, void* normed, void* cosv,
+                 void* sinv, void* stream);
+
 /* ---- multi-GPU: peer exchange of the per-rank attention records -----------------
  * Replaces the one all-gather per attention call of a sequence-sharded prefix (the reference has no counterpart:
  * `device_map="auto"`, llama_glide.py:474) by peer stores into IPC-mapped mailboxes + flags, so that a decode round

@@ -94,6 +94,7 @@ SYMBOLS = {
                                             _P, _P]),
     "ls_tree_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _I, _P, _I, _L, _P, _P, _P, _P, _I, _P, _I, _P, _P]),
     "ls_embed_rows": (C.c_int, [_P, _L, _I, _I, _P, _I, _P, _P]),
+    "ls_pass_head": (C.c_int, [_P, _L, _I, _I, _P, _I, _P, _P, _I, _I, _P, C.c_float, _P, C.c_float, _P, _P, _P, _P, _P]),
     "ls_chain_commit": (C.c_int, [_P, _P, _I, _I, _P, _L, _I, _P, _P, _P, _P, _I, _L, _P, _P, _P]),
     "ls_xchg_create": (C.c_int, [_I, _I, C.c_size_t, C.POINTER(_P)]),
     "ls_xchg_handle": (C.c_int, [_P, _P]),

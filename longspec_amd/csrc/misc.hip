@@ -71,20 +71,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const typename E::T* __res
 // tiles, 64-column slabs, groups of eight slabs in column order) -- the order in which the projections of gemm.hip produce and consume it, so
 // that a norm folded into the next projection and this kernel give the same bits.
 template <typename E, int NCH, bool CANON>
-__global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T* __restrict__ x,
-                                                            const typename E::T* __restrict__ res,
-                                                            const typename E::T* __restrict__ wgt, typename E::T* __restrict__ y,
-                                                            typename E::T* __restrict__ sum_out, int hidden, float eps) {
+__device__ __forceinline__ void rmsnorm_row(const typename E::T* __restrict__ xrow, const typename E::T* __restrict__ resrow,
+                                            const typename E::T* __restrict__ wgt, typename E::T* __restrict__ yrow,
+                                            typename E::T* __restrict__ sumrow, typename E::T* __restrict__ copyrow, int hidden,
+                                            float eps) {
+    // xrow / resrow / yrow / sumrow / copyrow: THIS row (workgroup) already; `copyrow`: x as loaded (pass_head: the gathered
+    // embedding row, the pass's residual stream)
     __shared__ float red[16];
-    const long base = (long)blockIdx.x * hidden;
     const int tid = threadIdx.x, T = blockDim.x;
     typename E::V8 v[NCH], r[NCH], w8[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = (c * T + tid) * 8;
         if (i < hidden) {
-            v[c] = *reinterpret_cast<const typename E::V8*>(x + base + i);
-            if (res) r[c] = *reinterpret_cast<const typename E::V8*>(res + base + i);
+            v[c] = *reinterpret_cast<const typename E::V8*>(xrow + i);
+            if (resrow) r[c] = *reinterpret_cast<const typename E::V8*>(resrow + i);
             w8[c] = *reinterpret_cast<const typename E::V8*>(wgt + i);
         }
     }
@@ -95,10 +96,11 @@ __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T*
         const int i = (c * T + tid) * 8;
         float s8 = 0.f;
         if (i < hidden) {
-            if (res) {
+            if (copyrow) *reinterpret_cast<typename E::V8*>(copyrow + i) = v[c];
+            if (resrow) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[c][e] = E::from_f32(E::to_f32(r[c][e]) + E::to_f32(v[c][e]));
-                if (sum_out) *reinterpret_cast<typename E::V8*>(sum_out + base + i) = v[c];
+                if (sumrow) *reinterpret_cast<typename E::V8*>(sumrow + i) = v[c];
             }
             if (CANON) {
                 s8 = ssq_quad(E::to_f32(v[c][0]), E::to_f32(v[c][1]), E::to_f32(v[c][2]), E::to_f32(v[c][3])) +
@@ -140,9 +142,57 @@ __global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T*
                 const float n = round_to<E>(E::to_f32(v[c][e]) * rs);
                 o[e] = E::from_f32(E::to_f32(w8[c][e]) * n);
             }
-            *reinterpret_cast<typename E::V8*>(y + base + i) = o;
+            *reinterpret_cast<typename E::V8*>(yrow + i) = o;
         }
     }
+}
+
+template <typename E, int NCH, bool CANON>
+__global__ __launch_bounds__(1024) void rmsnorm_rows_kernel(const typename E::T* __restrict__ x,
+                                                            const typename E::T* __restrict__ res,
+                                                            const typename E::T* __restrict__ wgt, typename E::T* __restrict__ y,
+                                                            typename E::T* __restrict__ sum_out, int hidden, float eps) {
+    const long base = (long)blockIdx.x * hidden;
+    rmsnorm_row<E, NCH, CANON>(x + base, res ? res + base : nullptr, wgt, y + base, sum_out ? sum_out + base : nullptr, nullptr, hidden, eps);
+}
+
+// cos/sin of one position, element j of 64: shared by rope_cos_sin_kernel and pass_head_kernel (the same bits)
+template <typename E>
+__device__ __forceinline__ void rope_row_entry(float posf, const float* __restrict__ inv_freq, float scaling, int j,
+                                               typename E::T* __restrict__ cosrow, typename E::T* __restrict__ sinrow) {
+    const float f = posf * inv_freq[j];
+    const float c = (float)cos((double)f) * scaling;
+    const float s = (float)sin((double)f) * scaling;
+    const typename E::T ce = E::from_f32(c), se = E::from_f32(s);
+    cosrow[j] = ce;
+    cosrow[64 + j] = ce;
+    sinrow[j] = se;
+    sinrow[64 + j] = se;
+}
+
+// Head of a decode pass in ONE launch (round 6): embedding gather (tree.hip: embed_rows_kernel) + the RoPE table of the pass
+// (rope_cos_sin_kernel) + the first layer's input RMSNorm (rmsnorm_rows_kernel) -- three 4-7 us latency-bound launches in front
+// of every draft pass, the verify pass and a vanilla step (profiles/r5_round_timeline_128k.json: 16.5 us per pass).  One
+// workgroup per token row; the same device functions as the three kernels, so the outputs are bit-identical to theirs.
+//   position of row i: positions[i] if given, else pos_base[i / q_len] + i % q_len + pos_add (the `arange + cache_lens[:, None]`
+//   of llama_glide.py:1005 / llama.py:571-577, without the elementwise launch).
+template <typename E, int NCH, bool CANON>
+__global__ __launch_bounds__(1024) void pass_head_kernel(const typename E::T* __restrict__ table, const int64_t* __restrict__ ids,
+                                                         long vocab, const int64_t* __restrict__ positions,
+                                                         const int32_t* __restrict__ pos_base, int q_len, int pos_add,
+                                                         const float* __restrict__ inv_freq, float scaling,
+                                                         const typename E::T* __restrict__ wgt, typename E::T* __restrict__ embeds,
+                                                         typename E::T* __restrict__ y, typename E::T* __restrict__ cosv,
+                                                         typename E::T* __restrict__ sinv, int hidden, float eps) {
+    const int row = blockIdx.x;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // memory safety, as embed_rows_kernel
+    if (threadIdx.x < 64) {
+        const long pos = positions ? positions[row] : (long)pos_base[row / q_len] + row % q_len + pos_add;
+        rope_row_entry<E>((float)pos, inv_freq, scaling, threadIdx.x, cosv + (long)row * 128, sinv + (long)row * 128);
+    }
+    const long base = (long)row * hidden;
+    rmsnorm_row<E, NCH, CANON>(table + id * (long)hidden, nullptr, wgt, y + base, nullptr, embeds + base, hidden, eps);
 }
 
 // ---- RoPE -------------------------------------------------------------------------------
@@ -155,14 +205,7 @@ __global__ void rope_cos_sin_kernel(const int64_t* __restrict__ pos, const float
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * 64) return;
     const int r = idx >> 6, j = idx & 63;
-    const float f = (float)pos[r] * inv_freq[j];
-    const float c = (float)cos((double)f) * scaling;
-    const float s = (float)sin((double)f) * scaling;
-    const typename E::T ce = E::from_f32(c), se = E::from_f32(s);
-    cosv[(long)r * 128 + j] = ce;
-    cosv[(long)r * 128 + 64 + j] = ce;
-    sinv[(long)r * 128 + j] = se;
-    sinv[(long)r * 128 + 64 + j] = se;
+    rope_row_entry<E>((float)pos[r], inv_freq, scaling, j, cosv + (long)r * 128, sinv + (long)r * 128);
 }
 
 // x*cos + rotate_half(x)*sin, each product and the sum rounded to dtype.
@@ -258,6 +301,44 @@ int ls_rmsnorm_fwd(const void* x, const void* residual, const void* weight, void
         hipLaunchKernelGGL(rmsnorm_kernel<ElemBF16>, dim3(rows), dim3(256), lds, s, (const __bf16*)x,
                            (const __bf16*)residual, (const __bf16*)weight, (__bf16*)y, (__bf16*)sum_out, hidden, eps);
     LS_CHECK_LAUNCH("rmsnorm_kernel");
+    return LS_OK;
+}
+
+int ls_pass_head(const void* table, int64_t vocab, int hidden, int dtype, const int64_t* ids, int rows, const int64_t* positions,
+                 const int32_t* pos_base, int q_len, int pos_add, const float* inv_freq, float attention_scaling,
+                 const void* norm_weight, float eps, void* embeds, void* normed, void* cosv, void* sinv, void* stream) {
+    if (!table || !ids || !inv_freq || !norm_weight || !embeds || !normed || !cosv || !sinv || vocab < 1 || rows < 1 || rows > 128 ||
+        hidden < 8 || (hidden & 7) || hidden / 8 > 4096 || (!positions && (!pos_base || q_len < 1)))
+        LS_FAIL(LS_ERR_INVALID_ARG, "pass_head args (rows %d <= 128, hidden %d)", rows, hidden);
+    if (dtype != LS_F16 && dtype != LS_BF16) LS_FAIL(LS_ERR_INVALID_ARG, "dtype %d", dtype);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunks = hidden / 8;
+    int T = ((chunks + 63) / 64) * 64;          // (>= 64: the first wave also writes the row's cos/sin)
+    int nch = 1;
+    if (T > 1024) {
+        nch = chunks <= 2048 ? 2 : 4;
+        T = (((chunks + nch - 1) / nch + 63) / 64) * 64;
+    }
+#define LS_PASS_HEAD(EL, TY, N)                                                                                           \
+    if (hidden % 64 == 0)                                                                                                 \
+        hipLaunchKernelGGL((pass_head_kernel<EL, N, true>), dim3(rows), dim3(T), 0, s, (const TY*)table, ids, (long)vocab, \
+                           positions, pos_base, q_len, pos_add, inv_freq, attention_scaling, (const TY*)norm_weight,      \
+                           (TY*)embeds, (TY*)normed, (TY*)cosv, (TY*)sinv, hidden, eps);                                  \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((pass_head_kernel<EL, N, false>), dim3(rows), dim3(T), 0, s, (const TY*)table, ids, (long)vocab, \
+                           positions, pos_base, q_len, pos_add, inv_freq, attention_scaling, (const TY*)norm_weight,      \
+                           (TY*)embeds, (TY*)normed, (TY*)cosv, (TY*)sinv, hidden, eps)
+    if (dtype == LS_F16) {
+        if (nch == 1) { LS_PASS_HEAD(ElemF16, _Float16, 1); }
+        else if (nch == 2) { LS_PASS_HEAD(ElemF16, _Float16, 2); }
+        else { LS_PASS_HEAD(ElemF16, _Float16, 4); }
+    } else {
+        if (nch == 1) { LS_PASS_HEAD(ElemBF16, __bf16, 1); }
+        else if (nch == 2) { LS_PASS_HEAD(ElemBF16, __bf16, 2); }
+        else { LS_PASS_HEAD(ElemBF16, __bf16, 4); }
+    }
+#undef LS_PASS_HEAD
+    LS_CHECK_LAUNCH("pass_head_kernel");
     return LS_OK;
 }
 

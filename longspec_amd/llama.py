@@ -354,12 +354,16 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps, ops=ops)
 
     def forward(self, hidden_states, position_embeddings, cache_lens=None, flex_attn=None, exec_type=None, tree_mask=None,
-                induction_head=False, tree_mask_bits=None, pending_residual=None, defer_residual=False):
+                induction_head=False, tree_mask_bits=None, pending_residual=None, defer_residual=False, prenormed=None):
         """``pending_residual``: the previous layer's MLP output has not been added to its residual stream yet;
         the sum (rounded to the storage dtype exactly like ``residual + hidden_states``, llama.py:492) is formed
         inside this layer's first norm kernel.  ``defer_residual``: return (mlp_out, residual) un-added for the
-        next norm to fuse."""
-        if pending_residual is None:
+        next norm to fuse.  ``prenormed``: ``input_layernorm(hidden_states)`` already computed by the pass's head launch
+        (``ops.pass_head``; first layer only)."""
+        if prenormed is not None:
+            residual = hidden_states
+            hidden_states = prenormed
+        elif pending_residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
@@ -396,7 +400,13 @@ class LlamaModel(nn.Module):
         shard = getattr(self.layers[0].self_attn, "shard", None)
         if shard is not None:
             shard.begin_pass()
-        if position_ids is None:                                    # llama.py:571-577
+        # decode-shaped passes (<= 128 token rows): embedding gather + RoPE table + the first layer's input norm are ONE launch
+        # (ops.pass_head, bit-identical to the three operators; the positions `arange + cache_lens` are formed inside it)
+        head = (inputs_embeds is None and position_embeddings is None and input_ids is not None and input_ids.dim() == 2
+                and cache_lens is not None and (position_ids is not None or tree_mask is None)
+                and getattr(self.ops, "pass_head", None) is not None and getattr(self.ops, "PASS_HEAD", True)
+                and self.ops.pass_head_supported(input_ids, self.embed_tokens.weight, self.layers[0].input_layernorm.weight))
+        if position_ids is None and not head:                       # llama.py:571-577
             if tree_mask is None:
                 position_ids = torch.arange(0, input_ids.size(1), device=input_ids.device)[None, :]
                 if cache_lens is not None:
@@ -405,6 +415,14 @@ class LlamaModel(nn.Module):
                 position_ids = self.ops.tree_positions(tree_mask, cache_lens)
         if tree_mask is not None and tree_mask_bits is None:
             tree_mask_bits = self.ops.pack_tree_mask(tree_mask)     # once per pass, shared by all layers
+        prenormed = None
+        if head:
+            rot, ln = self.rotary_emb, self.layers[0].input_layernorm
+            if rot.inv_freq.device != input_ids.device:
+                rot.inv_freq = rot.inv_freq.to(input_ids.device)
+            inputs_embeds, prenormed, position_embeddings = self.ops.pass_head(
+                self.embed_tokens.weight, input_ids, rot.inv_freq, rot.attention_scaling, ln.weight, ln.variance_epsilon,
+                position_ids=position_ids, pos_base=cache_lens if position_ids is None else None)
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
         hidden_states = inputs_embeds
@@ -414,7 +432,8 @@ class LlamaModel(nn.Module):
         for decoder_layer in self.layers:
             hidden_states, residual = decoder_layer(hidden_states, position_embeddings, cache_lens, flex_attn, exec_type,
                                                     tree_mask, induction_head, tree_mask_bits=tree_mask_bits,
-                                                    pending_residual=residual, defer_residual=True)
+                                                    pending_residual=residual, defer_residual=True, prenormed=prenormed)
+            prenormed = None
         hidden_states, _ = self.norm(hidden_states, residual=residual)
         return SimpleNamespace(last_hidden_state=hidden_states, past_key_values=None)
 

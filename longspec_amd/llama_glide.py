@@ -158,15 +158,16 @@ class LlamaGlideDecoderLayer(nn.Module):
         self.self_attn.prefill_cache_only(self.input_layernorm(hidden_states), position_embeddings)
 
     def forward(self, hidden_states, position_embeddings, llm_kv, cache_lens=None, exec_type=None, llm_kv_len=None,
-                tree_mask=None, tree_mask_bits=None):
-        """``tree_mask_bits``: the packed ``tree_mask`` when the caller already has it (``ops.tree_grow``)."""
+                tree_mask=None, tree_mask_bits=None, prenormed=None):
+        """``tree_mask_bits``: the packed ``tree_mask`` when the caller already has it (``ops.tree_grow``);
+        ``prenormed``: ``input_layernorm(hidden_states)`` when the pass's head launch (``ops.pass_head``) already formed it."""
         bits = tree_mask_bits
         if bits is None and tree_mask is not None:
             bits = self.ops.pack_tree_mask(tree_mask)
         if self.cross_attn.shard is not None:
             self.cross_attn.shard.begin_pass()
         residual = hidden_states
-        hidden_states = self.input_layernorm(hidden_states)
+        hidden_states = self.input_layernorm(hidden_states) if prenormed is None else prenormed
         hidden_states = self.self_attn(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                        cache_lens=cache_lens, exec_type="sa_" + exec_type, tree_mask=tree_mask,
                                        tree_mask_bits=bits)
@@ -233,6 +234,23 @@ class LlamaGlide(LlamaForCausalLM):
         self.model.set_kv_len_hint(target_bound)
         self.glide.self_attn.kv_len_hint = draft_bound
         self.glide.cross_attn.llm_kv_len_hint = target_bound
+
+    def _draft_head(self, ids, position_ids=None, pos_base=None, pos_add: int = 0):
+        """Head of a draft pass: ``embed_tokens(ids)``, the RoPE table of its positions (``position_ids`` [b,q] int64, or
+        ``arange(q) + pos_base[:, None] + pos_add``) and the draft layer's ``input_layernorm`` (``llama_glide.py:1003-1006,
+        1030-1033,437``).  One launch on the HIP operator layer (``ops.pass_head``), three operators otherwise (the CPU oracle
+        of the host-logic tests); returns (embeds, normed or None, position_embeddings)."""
+        ops, ln, rot = self.ops, self.glide.input_layernorm, self.model.rotary_emb
+        if (getattr(ops, "pass_head", None) is not None and getattr(ops, "PASS_HEAD", True)
+                and ops.pass_head_supported(ids, self.model.embed_tokens.weight, ln.weight)):
+            if rot.inv_freq.device != ids.device:
+                rot.inv_freq = rot.inv_freq.to(ids.device)
+            return ops.pass_head(self.model.embed_tokens.weight, ids, rot.inv_freq, rot.attention_scaling, ln.weight,
+                                 ln.variance_epsilon, position_ids=position_ids, pos_base=pos_base, pos_add=pos_add)
+        hidden_states = self.model.embed_tokens(ids)
+        if position_ids is None:
+            position_ids = torch.arange(ids.size(1), device=ids.device)[None, :] + pos_base[:, None] + pos_add
+        return hidden_states, None, self.model.rotary_emb(hidden_states, position_ids)
 
     def _stop_id(self, eos_id, loop: str):
         """Token whose appearance ends a loop.  The Llama twin tests ``self.config.eos_token_id`` in all
@@ -473,8 +491,12 @@ class LlamaGlide(LlamaForCausalLM):
             else:
                 draft_ids = spec_buffer[:, spec_steps, None]
                 position_ids = draft_cache_lens[:, None]
-            hidden_states = self.model.embed_tokens(draft_ids)
-            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            prenormed = None
+            if magic:
+                hidden_states = self.model.embed_tokens(draft_ids)
+                position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+            else:
+                hidden_states, prenormed, position_embeddings = self._draft_head(draft_ids, position_ids=position_ids)
             if magic:        # the target drafts for itself over its streaming cache (:830-836)
                 stream_lens = (draft_cache_lens - st.input_len.int() + st.stream_rows).to(torch.int32)
                 self.model.set_kv_len_hint(st.stream_rows + st.emitted + gamma + 2)
@@ -484,7 +506,7 @@ class LlamaGlide(LlamaForCausalLM):
             else:
                 hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                            llm_kv=self._last_kv(), cache_lens=draft_cache_lens,
-                                           llm_kv_len=cache_lens, exec_type="decoding")
+                                           llm_kv_len=cache_lens, exec_type="decoding", prenormed=prenormed)
             if st.double_flag and spec_steps == 0:
                 draft_cache_lens += 2                    # 1 + double_input (batch 1: the host knows the flag)
                 current_logp = self.lm_head(hidden_states[:, -2:, :])
@@ -797,12 +819,10 @@ class LlamaGlide(LlamaForCausalLM):
         # overwritten before they are read, but the ROW COUNT enters the bottom-right alignment of the causal cross-attention
         # (row i sees llm_kv_len - sq + i keys), so it is reproduced.
         n0 = a if st.temperature == 0 else st.d0_rows
-        hidden_states = self.model.embed_tokens(st.acc_pad[:, :n0])
-        position_ids = st.arange_g[:, :n0] + st.draft_cache_lens[:, None]
-        position_embeddings = self.model.rotary_emb(hidden_states, position_ids)
+        hidden_states, prenormed, position_embeddings = self._draft_head(st.acc_pad[:, :n0], pos_base=st.draft_cache_lens)
         hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                    llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
-                                   llm_kv_len=st.target_cache_lens_for_draft, exec_type="decoding")
+                                   llm_kv_len=st.target_cache_lens_for_draft, exec_type="decoding", prenormed=prenormed)
         # log_softmax + top-k of the draft's next-token distribution (:1019-1020), fused on the fp16 logits.  Under a shard
         # with `vocab_parallel` every rank multiplies by its slice of the lm_head only (dist.KVShard.head_select)
         vsh = last_attn.shard if (last_attn.shard is not None and last_attn.shard.vocab_parallel and st.temperature == 0) else None
@@ -823,12 +843,11 @@ class LlamaGlide(LlamaForCausalLM):
         # ---- D1..: tree levels (:1029-1075)
         for ms in range(1, gamma):
             lo, mid = acc_n[ms - 1], acc_n[ms]
-            hidden_states = self.model.embed_tokens(all_spec[:, lo:mid])
-            position_embeddings = self.model.rotary_emb(hidden_states, position_ids)                    # p + depth (:1032)
+            hidden_states, prenormed, position_embeddings = self._draft_head(all_spec[:, lo:mid], position_ids=position_ids)   # p + depth (:1032)
             hidden_states = self.glide(hidden_states=hidden_states, position_embeddings=position_embeddings,
                                        llm_kv=self._last_kv(), cache_lens=st.draft_cache_lens,
                                        llm_kv_len=st.target_cache_lens_for_draft, exec_type="tree_decoding",
-                                       tree_mask=tree_mask[:, lo:mid, :mid], tree_mask_bits=mask_bits)
+                                       tree_mask=tree_mask[:, lo:mid, :mid], tree_mask_bits=mask_bits, prenormed=prenormed)
             # log_softmax + cumulative log-prob + flat top-k over (node, token) (:1046-1064), one fused operator
             if vsh is not None:
                 topk_logp_sum, topk_indices = vsh.head_select(self.lm_head, hidden_states, ops, k=cand[ms],

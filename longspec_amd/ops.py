@@ -19,6 +19,7 @@ no fallback: a missing extension or a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional, Tuple
 
@@ -1100,12 +1101,51 @@ def chain_commit(llm_verify_output, spec_buffer, output_ids, cache_lens, draft_c
 
 
 EMBED_MAX_ROWS = 128
+# one launch for embedding gather + RoPE table + first input norm of a decode pass (ls_pass_head); LONGSPEC_PASS_HEAD=0 keeps the
+# three operators (A/B measurements; the results are bit-identical either way)
+PASS_HEAD = os.environ.get("LONGSPEC_PASS_HEAD", "1") != "0"
 
 
 def embed_supported(ids: torch.Tensor, weight: torch.Tensor) -> bool:
     """Short passes gather their embedding rows with ``ls_embed_rows``; prefill-sized inputs use the library."""
     return (ids.is_cuda and weight.is_cuda and 0 < ids.numel() <= EMBED_MAX_ROWS and weight.dtype in (torch.float16, torch.bfloat16)
             and weight.is_contiguous() and weight.shape[1] % 8 == 0)
+
+
+def pass_head(weight: torch.Tensor, ids: torch.Tensor, inv_freq: torch.Tensor, attention_scaling: float, norm_weight: torch.Tensor,
+              eps: float, position_ids: Optional[torch.Tensor] = None, pos_base: Optional[torch.Tensor] = None, pos_add: int = 0):
+    """Head of a decode pass in one launch: ``embed_tokens(ids)``, the pass's RoPE table and the first layer's
+    ``input_layernorm`` (``llama.py:579-580`` + ``LlamaDecoderLayer.forward``; ``llama_glide.py:1003-1006,1030-1033,437``).
+    ids [b,q] int64; positions = ``position_ids`` [b,q] int64, or ``arange(q) + pos_base[:, None] + pos_add`` (pos_base [b] int32).
+    Returns (embeds [b,q,hidden], normed [b,q,hidden], (cos, sin) [b,q,128]); bit-identical to the three separate operators."""
+    _dev(weight, ids, inv_freq, norm_weight, position_ids, pos_base)
+    b, q = ids.shape
+    flat = ids.to(torch.int64).contiguous().view(-1)
+    hidden = weight.shape[1]
+    dev = weight.device
+    buf = torch.empty((2, b, q, hidden), dtype=weight.dtype, device=dev)
+    cs = torch.empty((2, b, q, 128), dtype=weight.dtype, device=dev)
+    if position_ids is not None:
+        pos = position_ids.to(torch.int64).contiguous()
+        if pos.numel() != b * q:
+            raise ValueError(f"pass_head: {pos.numel()} positions for {b * q} token rows")
+        pos_p, base_p = pos.data_ptr(), None
+    else:
+        if pos_base is None or pos_base.numel() != b:
+            raise ValueError("pass_head: position_ids [b,q] int64 or pos_base [b] int32")
+        pos_base = pos_base if pos_base.dtype == torch.int32 else pos_base.to(torch.int32)
+        pos_base = pos_base.contiguous()
+        pos_p, base_p = None, pos_base.data_ptr()
+    lib = _C.load()
+    _C.check(lib.ls_pass_head(weight.data_ptr(), weight.shape[0], hidden, _dtype(weight), flat.data_ptr(), b * q, pos_p, base_p, q,
+                              int(pos_add), inv_freq.data_ptr(), float(attention_scaling), norm_weight.data_ptr(), float(eps),
+                              buf[0].data_ptr(), buf[1].data_ptr(), cs[0].data_ptr(), cs[1].data_ptr(), _stream()), "ls_pass_head")
+    return buf[0], buf[1], (cs[0], cs[1])
+
+
+def pass_head_supported(ids: torch.Tensor, weight: torch.Tensor, norm_weight: torch.Tensor) -> bool:
+    return (embed_supported(ids, weight) and ids.dim() == 2 and ids.numel() <= 128 and weight.shape[1] // 8 <= 4096
+            and norm_weight.dtype == weight.dtype and norm_weight.is_cuda)
 
 
 def embed_rows(weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
