@@ -12,8 +12,8 @@ done
 python - <<PY
 import glob, json, sqlite3
 from collections import defaultdict
-KERNELS = {"attention_ws": "attn_partial_ws_kernel", "gemm_gate_up_M74": "skinny_gemm_kernel<ElemF16, 5, 8, 1>",
-           "gemm_qkv_rope_M74": "skinny_gemm_kernel<ElemF16, 5, 4, 2>", "gemm_lm_head_draft": None}
+KERNELS = {"attention_ws": "attn_partial_ws_kernel", "gemm_gate_up_M74": "skinny_gemm_kernel<ElemF16, 5, 8, 1,",
+           "gemm_qkv_rope_M74": "skinny_gemm_kernel<ElemF16, 5, 4, 2,", "gemm_lm_head_draft": None}
 out = {k: {} for k in KERNELS if KERNELS[k]}
 for db in sorted(glob.glob("/tmp/prk_*/**/*.db", recursive=True)):
     c = sqlite3.connect(db)
