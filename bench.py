@@ -414,6 +414,10 @@ def main():
         return
     if args.share_gpu:
         local_rank = 0
+        if world > 1 and args.backend != "gloo":     # RCCL refuses two ranks on one device ("Duplicate GPU detected")
+            if rank == 0:
+                print("[bench] --share-gpu: ranks share cuda:0, the collective backend is gloo", file=sys.stderr, flush=True)
+            args.backend = "gloo"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL, hipIpc mailboxes): before the runtime starts
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
