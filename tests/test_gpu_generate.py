@@ -307,6 +307,92 @@ def test_soak_long_generation_crosses_graph_tiers():
             f"tree and vanilla part at {k} on a margin of {margin:.1f} ulps"
 
 
+@pytest.mark.parametrize("where", ["before_the_warm_up", "in_a_replay"])
+def test_vanilla_step_loses_no_token_when_its_graph_fails(where):
+    """a failure in the graph path of `vanilla_step` IN FRONT of the warm-up step (hint sizing, stream wait) or in a
+    later `replay()` left the step's token undecoded (a 0 in output_ids, cache_lens not advanced).  Both must fall through to
+    the eager step: the generation equals the plain one token for token."""
+    import warnings
+    run = [r for r in cases.generate_runs() if r["name"] == "mixed"][0]
+    args = (run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"))
+    m = build(run)
+    want = m.vanilla_generate(*args, max_gen_len=run["max_gen_len"])[0].cpu()
+    assert torch.equal(want, run["vanilla_out"])
+    m2 = build(run)
+    m2.GRAPH_AFTER = 3
+    if where == "before_the_warm_up":
+        def boom(*a, **k):
+            raise RuntimeError("injected: tier sizing failed")
+        m2._tier_bound = boom
+    else:
+        real = torch.cuda.CUDAGraph.replay
+        calls = {"n": 0}
+
+        def flaky(self):
+            calls["n"] += 1
+            if calls["n"] == 3:
+                raise RuntimeError("injected: replay failed")
+            return real(self)
+        torch.cuda.CUDAGraph.replay = flaky
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = m2.vanilla_generate(*args, max_gen_len=run["max_gen_len"])[0].cpu()
+    finally:
+        if where != "before_the_warm_up":
+            torch.cuda.CUDAGraph.replay = real
+    assert any("running eagerly" in str(x.message) for x in w), "the injected failure was not hit"
+    assert torch.equal(got, want)
+
+
+def test_stochastic_rounds_size_their_launches_by_a_per_round_bound():
+    """at temperature > 0 every round sized its launches for P + the WHOLE token budget.  It is P + the tokens accepted
+    so far (+ the round's speculative rows) now -- an upper bound of every cache length, so the result must not move: the same seeded
+    generation with the hints forced to the whole budget (the old behaviour) and with the per-round bound, token for token."""
+    import random
+    from longspec_amd import ops
+    run = list(cases.stochastic_runs())[0]
+    budget = 4 * run["max_gen_len"]                     # room to grow: the per-round bound stays far below the budget
+
+    def go(force_budget):
+        m = build(run)
+        seen = []
+        if force_budget:
+            orig = m._set_hints
+            big = run["prompt_len"] + budget + 512
+            m._set_hints = lambda t, d: orig(big, big)
+        else:
+            orig = m._set_hints
+
+            def spy(t, d):
+                seen.append(int(t))
+                return orig(t, d)
+
+            m._set_hints = spy
+        ops.stochastic_noise_fn = lambda V, dtype, device: torch.empty(V, dtype=dtype).exponential_(1).to(device)
+        try:
+            random.seed(4242)
+            torch.manual_seed(4243)
+            try:
+                out, count, num, _, _ = m.tree_spec_generate(run["prompt"].cuda(), torch.tensor([run["prompt_len"]], device="cuda"),
+                                                             tree_shape=run["tree_shape"], max_gen_len=budget,
+                                                             temperature=run["temperature"])
+            except RuntimeError as e:                   # gamma + 2 accepted tokens: the reference raises too (:1081)
+                assert "verification batch" in str(e)
+                return None, seen
+        finally:
+            ops.stochastic_noise_fn = None
+        return (out.cpu(), int(count), int(num)), seen
+
+    new, seen = go(False)
+    old, _ = go(True)
+    assert (new is None) == (old is None)
+    if new is not None:
+        assert torch.equal(new[0], old[0]) and new[1:] == old[1:]
+    # the bound follows the generation instead of sitting at the budget from round 1
+    assert len(seen) > 3 and seen[1] < run["prompt_len"] + budget // 2 and all(b >= a for a, b in zip(seen[1:], seen[2:]))
+
+
 @pytest.mark.parametrize("run", list(cases.stochastic_runs(long=True)), ids=lambda r: r["name"])
 def test_long_tree_run_with_temperature(run):
     """tree_spec_generate(temperature = 0.8) through a truncating draft window for 65-67 rounds on the HIP kernels, with the
